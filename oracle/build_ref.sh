@@ -1,0 +1,102 @@
+#!/usr/bin/env bash
+# TEST INFRASTRUCTURE ONLY -- builds the *real* reference (GALAHAD SLS + SPRAL SSIDS CPU backend)
+# from the sources where they lie under /root/reference, for use as the parity checker and as the
+# "reference" CPU baseline.  Nothing under galahad_amd/ may link or call what this produces.
+#
+# * sources are compiled in place (never copied into the repo); the throw-away header layout the
+#   C++ files expect (the same one src/spral/makemaster:270-300 stages with cp + seds/have_hwloc_undef.sed)
+#   lives in a scratch dir under /tmp and is deleted afterwards;
+# * outputs go ONLY to oracle/_ref/ (git-ignored, but shipped to the GPU box by gpurun):
+#       oracle/_ref/libgalahad_ref.so   reference SLS/SSIDS/LAPACK objects
+#       oracle/_ref/ref_driver          our driver (oracle/ref_driver.f90) linked against it
+# * the reference's own build system (bin/install_galahad, makemaster files) is NOT run.
+#
+# Toolchain notes: g++ for the C++11/OpenMP files (clang rejects default(none)
+# uses in assemble.hxx), amdflang for Fortran; fkeep.F90 is a preprocessed source, so the `untied`
+# task clause that makes amdflang-22 ICE is dropped with -Duntied= (semantics unchanged: an untied
+# task may simply not migrate between threads).
+set -euo pipefail
+
+REF=${GSLS_REFERENCE_ROOT:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+if [ ! -d "$REF/src/ssids" ]; then
+  echo "build_ref: $REF not present -- keeping whatever prebuilt files are in $OUT" >&2
+  exit 0
+fi
+W=$(mktemp -d /tmp/gsls_ref_build.XXXXXX)
+trap 'rm -rf "$W"' EXIT
+mkdir -p "$OUT" "$W/inc/ssids/cpu/kernels" "$W/inc/hw_topology" "$W/mod" "$W/obj"
+S=$REF/src
+
+FC=${FC:-amdflang}
+CXX=${CXX:-g++}
+OPT=${GSLS_REF_OPT:--O2}
+FFLAGS="$OPT -fopenmp -fPIC -module-dir $W/mod -I$W/mod"
+CXXFLAGS="-std=c++11 $OPT -fopenmp -fPIC -I$W/inc"
+
+# ---- header layout (scratch only) -------------------------------------------------------------
+cp $S/ssids/cpu/*.hxx            $W/inc/ssids/cpu/
+cp $S/ssids/cpu/kernels/*.hxx    $W/inc/ssids/cpu/kernels/
+cp $S/ssids/profile.hxx $S/ssids/contrib.h $W/inc/ssids/
+cp $S/spral/omp.hxx $S/spral/compat.hxx   $W/inc/
+cp $S/spral/guess_topology.hxx $S/spral/hwloc_wrapper.hxx $W/inc/hw_topology/
+sed -f $REF/seds/have_hwloc_undef.sed $S/spral/config.h > $W/inc/config.h
+
+# ---- C++ (SSIDS CPU numeric backend) -----------------------------------------------------------
+pids=()
+for f in spral/compat spral/omp spral/guess_topology ssids/profile \
+         ssids/cpu/NumericSubtree ssids/cpu/SymbolicSubtree ssids/cpu/ThreadStats \
+         ssids/cpu/kernels/cholesky ssids/cpu/kernels/ldlt_app ssids/cpu/kernels/ldlt_nopiv \
+         ssids/cpu/kernels/ldlt_tpp ssids/cpu/kernels/wrappers ; do
+  o=$W/obj/cxx_$(basename $f).o
+  # -iquote- style trick: compile from the scratch inc dir so that quote-includes resolve to the
+  # staged headers (and the hwloc-less config.h), not to the ones next to the source file.
+  ( cd $W/inc && $CXX $CXXFLAGS -c -o $o -x c++ - < $S/$f.cxx ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+
+# ---- Fortran, in dependency order ---------------------------------------------------------------
+fc() { # fc <path relative to src> [extra flags]
+  local src=$1; shift
+  local o=$W/obj/f_$(echo $src | tr '/.' '__').o
+  $FC $FFLAGS "$@" -c -o $o $S/$src
+}
+ff() { # fixed-form F77, compiled in parallel (no modules produced)
+  local src=$1
+  local o=$W/obj/f_$(echo $src | tr '/.' '__').o
+  $FC $OPT -fPIC -module-dir $W/mod -I$W/mod -c -o $o $S/$src
+}
+# big F77 files first, in the background
+ff lapack/blas.f & p1=$!
+ff lapack/lapack.f & p2=$!
+ff lapack/ieeeck.f & p3=$!
+for f in spral/matrix_util.f90 spral/random.f90 spral/rutherford_boeing.f90 spral/cuda_nocuda.f90 \
+         spral/hw_topology.f90 spral/metis4_wrapper.f90 spral/scaling.f90 spral/match_order.f90 \
+         ssids/datatypes.f90 spral/core_analyse.f90 spral/pgm.f90 \
+         ssids/inform.f90 ssids/contrib.f90 ssids/subtree.f90 ssids/akeep.f90 ssids/cpu_iface.f90 \
+         ssids/cpu_subtree.f90 ssids/profile_iface.f90 ssids/gpu_subtree_no_cuda.f90 ssids/anal.f90 ; do
+  fc $f
+done
+fc ssids/fkeep.F90 -cpp -Duntied=
+fc ssids/ssids.f90
+fc ssids/contrib_free.f90
+for p in symbols clock string zd11 smt space specfile sort ; do fc $p/$p.f90 ; done
+for f in dum/ma27d.f dum/mc61d.f dum/mc77d.f dum/mc64d.f dum/metis.f ; do ff $f ; done
+fc lapack/blas_interface.f90
+fc lapack/lapack_interface.f90
+fc sils/sils.f90
+for f in hsl_zb01i hsl_of01i hsl_of01d hsl_mc78i hsl_mc34d hsl_ma57d hsl_ma77d hsl_ma86d hsl_ma87d \
+         hsl_ma97d hsl_mc64d hsl_mc68i ; do fc dum/$f.f90 ; done
+fc non-free/mkl/mkl_pardiso_interface.f90
+fc dum/mkl_pardiso.f90
+fc dum/pardiso.f90
+fc dum/wsmp.f90
+fc sls/sls.f90
+wait $p1 $p2 $p3
+
+# ---- link ------------------------------------------------------------------------------------------
+$FC -fopenmp -shared -o $OUT/libgalahad_ref.so $W/obj/*.o -lstdc++
+$FC $FFLAGS -o $OUT/ref_driver $HERE/ref_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
+echo "build_ref: wrote $OUT/libgalahad_ref.so and $OUT/ref_driver"

@@ -1,0 +1,110 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/): file I/O around oracle/_ref/ref_driver, the REAL reference
+(GALAHAD SLS + SPRAL SSIDS CPU) built by oracle/build_ref.sh.  Only tests/, bench.py's cpu_baseline
+leg, __graft_entry__.smoke() and the fixture generator may import this; the product never does.
+The binary layout is documented at the top of oracle/ref_driver.f90.
+"""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+MAGIC = 1397509959
+SOLVERS = {"ssids": 0, "sytr": 1, "potr": 2, "pbtr": 3}
+
+
+def available():
+    return os.path.exists(DRIVER) and os.access(DRIVER, os.X_OK)
+
+
+def write_problem(path, n, row, col, val, rhs, *, solver="ssids", pivot_control=1, max_refine=0,
+                  nemin=0, perm=None, repeat=1, dump_struct=False, scaling=0, ordering=-999,
+                  relative_pivot_tolerance=-1.0, absolute_pivot_tolerance=-1.0):
+    """row/col/perm are 1-based (Fortran) int32 arrays; rhs is (n,) or (n, nrhs) column-major."""
+    row = np.ascontiguousarray(row, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    rhs = np.asarray(rhs, dtype=np.float64)
+    nrhs = 1 if rhs.ndim == 1 else rhs.shape[1]
+    rhs_f = np.asfortranarray(rhs.reshape(n, nrhs))
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2i", MAGIC, 1))
+        f.write(struct.pack("<12i", n, len(row), nrhs, SOLVERS[solver], pivot_control, max_refine,
+                            nemin, 0 if perm is None else 1, repeat, int(dump_struct), scaling,
+                            ordering))
+        f.write(struct.pack("<2d", relative_pivot_tolerance, absolute_pivot_tolerance))
+        f.write(row.tobytes())
+        f.write(col.tobytes())
+        f.write(val.tobytes())
+        if perm is not None:
+            f.write(np.ascontiguousarray(perm, dtype=np.int32).tobytes())
+        f.write(rhs_f.tobytes(order="F"))
+
+
+def read_result(path, n, nrhs, dump_struct):
+    with open(path, "rb") as f:
+        buf = f.read()
+    o = 0
+
+    def take(fmt, cnt=1):
+        nonlocal o
+        dt = np.dtype(fmt)
+        a = np.frombuffer(buf, dtype=dt, count=cnt, offset=o)
+        o += dt.itemsize * cnt
+        return a
+
+    st = take("<i4", 3)
+    big = take("<i8", 2)
+    ints = take("<i4", 8)
+    tms = take("<f8", 5)
+    x = take("<f8", n * nrhs).reshape(nrhs, n).T.copy()
+    res = dict(status_analyse=int(st[0]), status_factorize=int(st[1]), status_solve=int(st[2]),
+               entries_in_factors=int(big[0]), flops_elimination=int(big[1]),
+               rank=int(ints[0]), negative_eigenvalues=int(ints[1]), two_by_two=int(ints[2]),
+               delayed=int(ints[3]), max_front=int(ints[4]), max_depth=int(ints[5]),
+               num_sup=int(ints[6]),
+               t_analyse=float(tms[0]), t_factorize=float(tms[1]), t_solve=float(tms[2]),
+               t_factorize_median=float(tms[3]), t_solve_median=float(tms[4]),
+               x=x[:, 0] if nrhs == 1 else x)
+    if dump_struct:
+        flag, nn = (int(v) for v in take("<i4", 2))
+        res["struct_flag"] = flag
+        res["nnodes"] = nn
+        if flag >= 0:
+            res["sptr"] = take("<i4", nn + 1).copy()
+            res["sparent"] = take("<i4", nn).copy()
+            res["rptr"] = take("<i8", nn + 1).copy()
+            res["rlist"] = take("<i4", int(res["rptr"][-1]) - 1).copy()
+            res["order"] = take("<i4", n).copy()
+            nf = take("<i8", 2)
+            res["num_factor"], res["num_flops"] = int(nf[0]), int(nf[1])
+            res["nptr"] = take("<i8", nn + 1).copy()
+            nz = int(res["nptr"][-1]) - 1
+            res["nlist"] = take("<i8", 2 * nz).reshape(nz, 2).copy()
+    return res
+
+
+def run(n, row, col, val, rhs, *, threads=None, timeout=3600, **kw):
+    """Run the reference on one problem; returns the dict of read_result()."""
+    if not available():
+        raise RuntimeError("oracle/_ref/ref_driver not built (run oracle/build_ref.sh)")
+    rhs = np.asarray(rhs, dtype=np.float64)
+    nrhs = 1 if rhs.ndim == 1 else rhs.shape[1]
+    with tempfile.TemporaryDirectory(prefix="gsls_ref_") as d:
+        pin, pout = os.path.join(d, "p.bin"), os.path.join(d, "r.bin")
+        write_problem(pin, n, row, col, val, rhs, **kw)
+        env = dict(os.environ)
+        env["OMP_CANCELLATION"] = "true"          # SSIDS requirement (ssids.f90:1425-1460)
+        env.setdefault("OMP_PROC_BIND", "true")
+        if threads is not None:
+            env["OMP_NUM_THREADS"] = str(threads)
+        # n >~ 1e6 needs an unlimited stack for SLS's automatic arrays (sls.f90:8436)
+        cmd = "ulimit -s unlimited 2>/dev/null; exec '%s' '%s' '%s'" % (DRIVER, pin, pout)
+        p = subprocess.run(["bash", "-c", cmd], env=env, capture_output=True, text=True,
+                           timeout=timeout)
+        if p.returncode != 0 or not os.path.exists(pout):
+            raise RuntimeError("ref_driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
+        return read_result(pout, n, nrhs, kw.get("dump_struct", False))
