@@ -1,0 +1,478 @@
+// C ABI of the gsls backend (include/gsls.h): handle management, host<->HBM staging, status and
+// statistics.  Behavioural model: the SSIDS driver routines SLS calls
+//   ssids_analyse  src/ssids/ssids.f90:148-392      ssids_factor  :770-1108
+//   ssids_solve    :1114-1249                       ssids_enquire_* :1255-1341
+//   ssids_alter    :1347-1384                       ssids_free    :1388-1419
+// There is deliberately no CPU numeric path: without a HIP device factor/solve fail with -51.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gsls_device.hpp"
+
+using namespace gsls;
+
+namespace {
+
+struct Handle {
+  Symbolic S;
+  DeviceFactor F;
+  bool analysed = false, factored = false, posdef = false, dev_ready = false, have_scale = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  gsls_inform last;  // statistics of analyse (+factor), returned again by later phases
+  double kt_fwd = 0, kt_diag = 0, kt_bwd = 0;
+};
+
+double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int fail_hip(Handle* h, gsls_inform* inf, hipError_t e) {
+  if (inf) {
+    inf->flag = GSLS_ERROR_HIP;
+    inf->hip_error = int(e);
+  }
+  if (h) h->last.flag = GSLS_ERROR_HIP;
+  return GSLS_ERROR_HIP;
+}
+
+hipError_t ensure_device(Handle* h, const gsls_options* o) {
+  if (h->stream) return hipSuccess;
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess) return e;
+  if (cnt <= 0) return hipErrorNoDevice;
+  int dev = (o && o->device >= 0) ? o->device : -1;
+  if (dev < 0) {
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+  }
+  h->device = dev;
+  e = hipSetDevice(dev);
+  if (e != hipSuccess) return e;
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return e;
+  for (auto& ev : h->ev) {
+    e = hipEventCreate(&ev);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+struct DeviceGuard {  // leave the caller's current device untouched (cf. gpu_interfaces.f90:439-465)
+  int prev = -1;
+  bool active = false;
+  explicit DeviceGuard(int dev) {
+    if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) {
+      active = (hipSetDevice(dev) == hipSuccess);
+    }
+  }
+  ~DeviceGuard() {
+    if (active) (void)hipSetDevice(prev);
+  }
+};
+
+void fill_from_symbolic(const Symbolic& S, gsls_inform* inf) {
+  inf->matrix_rank = S.nnodes ? S.sptr[S.nnodes] : 0;
+  inf->maxdepth = S.maxdepth;
+  inf->maxfront = S.maxfront;
+  inf->num_factor = S.num_factor;
+  inf->num_flops = S.num_flops;
+  inf->num_sup = S.nnodes;
+  inf->nlevels = S.nlevels;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gsls_version(void) { return "gsls 0.1 (gfx950)"; }
+
+int gsls_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+
+void gsls_default_options(gsls_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->print_level = -1;
+  o->ordering = GSLS_ORDER_ND;
+  o->nemin = 32;
+  o->scaling = 0;
+  o->action = 1;
+  o->device = -1;
+  o->use_graph = 1;
+  o->u = 0.01;
+  o->small = 1e-20;
+  o->multiplier = 1.1;
+}
+
+int gsls_create(void** handle) {
+  if (!handle) return GSLS_ERROR_UNKNOWN;
+  Handle* h = new (std::nothrow) Handle();
+  if (!h) return GSLS_ERROR_ALLOCATION;
+  std::memset(&h->last, 0, sizeof(h->last));
+  *handle = h;
+  return GSLS_SUCCESS;
+}
+
+int gsls_destroy(void** handle) {
+  if (!handle || !*handle) return GSLS_SUCCESS;
+  Handle* h = static_cast<Handle*>(*handle);
+  {
+    DeviceGuard g(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    dev_free(h->F);
+    for (auto& ev : h->ev)
+      if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+  *handle = nullptr;
+  return GSLS_SUCCESS;
+}
+
+int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row, int32_t* order,
+                 const gsls_options* options, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  std::memset(inform, 0, sizeof(*inform));
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  gsls_options defo;
+  if (!options) {
+    gsls_default_options(&defo);
+    options = &defo;
+  }
+  const double t0 = now();
+  h->analysed = h->factored = h->dev_ready = false;
+  if (n < 0) return inform->flag = GSLS_ERROR_A_N_OOR;
+  if (n > 0 && (!ptr || !row)) return inform->flag = GSLS_ERROR_A_PTR;
+  if (n > 0 && ptr[0] != 1) return inform->flag = GSLS_ERROR_A_PTR;
+  for (int j = 0; j < n; ++j)
+    if (ptr[j + 1] < ptr[j]) return inform->flag = GSLS_ERROR_A_PTR;
+  if (options->ordering < 0 || options->ordering > 3) return inform->flag = GSLS_ERROR_ORDER;
+  int flag;
+  try {
+    if (n == 0) {
+      h->S = Symbolic();
+      flag = GSLS_SUCCESS;
+    } else {
+      for (int64_t k = 0; k < ptr[n] - 1; ++k)
+        if (row[k] < 1 || row[k] > n) return inform->flag = GSLS_ERROR_A_ALL_OOR;
+      flag = symbolic_analyse(n, ptr, row, order, options->ordering, options->nemin, h->S);
+    }
+  } catch (const std::bad_alloc&) {
+    inform->stat = 1;
+    return inform->flag = GSLS_ERROR_ALLOCATION;
+  }
+  inform->flag = flag;
+  if (flag < 0) return flag;
+  fill_from_symbolic(h->S, inform);
+  inform->factor_bytes = 8 * (h->S.nnodes ? h->S.loff[h->S.nnodes] : 0) + 16 * int64_t(n);
+  h->analysed = true;
+  inform->time_analyse = now() - t0;
+  h->last = *inform;
+  return flag;
+}
+
+static int factor_common(Handle* h, int posdef, const double* val, const double* scale, bool on_device,
+                         const gsls_options* options, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  if (!h || !h->analysed) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  inform->hip_error = 0;
+  gsls_options defo;
+  if (!options) {
+    gsls_default_options(&defo);
+    options = &defo;
+  }
+  const Symbolic& S = h->S;
+  h->factored = false;
+  if (S.n == 0) {
+    h->factored = true;
+    h->posdef = posdef != 0;
+    return GSLS_SUCCESS;
+  }
+  if (!val) return inform->flag = GSLS_ERROR_VAL;
+  const double t0 = now();
+  hipError_t e = ensure_device(h, options);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  DeviceGuard g(h->device);
+  if (!h->dev_ready) {
+    e = dev_upload_symbolic(S, h->F, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    h->dev_ready = true;
+  }
+  DeviceFactor& F = h->F;
+  const double* d_val = val;
+  const double* d_scale = scale;
+  if (!on_device) {
+    // ptr/row are not kept (check=.false. semantics, ssids.f90:869-877): the value count is the
+    // number of scattered entries
+    const int64_t nz = F.nscatter;
+    if (F.val_cap < nz) {
+      if (F.val) (void)hipFree(F.val);
+      F.val = nullptr;
+      e = hipMalloc(reinterpret_cast<void**>(&F.val), std::max<int64_t>(nz, 1) * sizeof(double));
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      F.val_cap = nz;
+    }
+    e = hipMemcpyAsync(F.val, val, nz * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    d_val = F.val;
+    if (scale) {
+      if (!F.scale) {
+        e = hipMalloc(reinterpret_cast<void**>(&F.scale), S.n * sizeof(double));
+        if (e != hipSuccess) return fail_hip(h, inform, e);
+      }
+      e = hipMemcpyAsync(F.scale, scale, S.n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      d_scale = F.scale;
+    }
+  } else if (scale) {
+    if (!F.scale) {
+      e = hipMalloc(reinterpret_cast<void**>(&F.scale), S.n * sizeof(double));
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+    }
+    e = hipMemcpyAsync(F.scale, scale, S.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    d_scale = F.scale;
+  }
+  h->have_scale = (scale != nullptr);
+  e = dev_factor(S, F, posdef != 0, d_val, d_scale, options->small, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  int32_t st[16];
+  e = hipMemcpyAsync(st, F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+
+  h->posdef = posdef != 0;
+  inform->num_neg = 0;
+  inform->num_two = 0;
+  inform->num_delay = 0;
+  inform->matrix_rank = S.sptr[S.nnodes];
+  if (posdef) {
+    if (st[0] != INT_MAX) {
+      inform->flag = GSLS_ERROR_NOT_POS_DEF;
+      h->last.flag = inform->flag;
+      inform->time_factor = now() - t0;
+      return inform->flag;
+    }
+  } else {
+    inform->num_neg = st[2];
+    inform->num_two = st[3];
+    inform->num_delay = st[4];
+    if (st[1] > 0) {
+      inform->matrix_rank -= st[1];
+      if (!options->action) {
+        inform->flag = GSLS_ERROR_SINGULAR;
+        inform->time_factor = now() - t0;
+        return inform->flag;
+      }
+      inform->flag = GSLS_WARNING_FACT_SINGULAR;
+    }
+  }
+  h->factored = true;
+  inform->time_factor = now() - t0;
+  h->last = *inform;
+  return inform->flag;
+}
+
+int gsls_factor(void* handle, int32_t posdef, const double* val, const double* scale,
+                const gsls_options* options, gsls_inform* inform) {
+  return factor_common(static_cast<Handle*>(handle), posdef, val, scale, false, options, inform);
+}
+
+int gsls_factor_dev(void* handle, int32_t posdef, const double* d_val, const double* d_scale,
+                    const gsls_options* options, gsls_inform* inform) {
+  return factor_common(static_cast<Handle*>(handle), posdef, d_val, d_scale, true, options, inform);
+}
+
+static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool on_device,
+                        gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  if (!h || !h->analysed || !h->factored) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  const Symbolic& S = h->S;
+  if (job < GSLS_SOLVE_JOB_ALL || job > GSLS_SOLVE_JOB_DIAG_BWD) return inform->flag = GSLS_ERROR_JOB_OOR;
+  if (h->posdef && (job == GSLS_SOLVE_JOB_DIAG || job == GSLS_SOLVE_JOB_DIAG_BWD))
+    return inform->flag = GSLS_ERROR_JOB_OOR;  // ssids.f90:1205-1210
+  if (nrhs < 1 || ldx < S.n || (!x && S.n > 0)) return inform->flag = GSLS_ERROR_X_SIZE;
+  if (S.n == 0) return GSLS_SUCCESS;
+  const double t0 = now();
+  DeviceGuard g(h->device);
+  DeviceFactor& F = h->F;
+  hipError_t e;
+  double* d_x = x;
+  const int64_t xelems = int64_t(ldx) * (nrhs - 1) + S.n;
+  if (!on_device) {
+    if (F.xhost) (void)hipFree(F.xhost);
+    F.xhost = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&F.xhost), xelems * sizeof(double));
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    e = hipMemcpyAsync(F.xhost, x, xelems * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    d_x = F.xhost;
+  }
+  e = dev_solve(S, F, h->posdef, job, nrhs, d_x, ldx, h->have_scale ? F.scale : nullptr, h->stream, h->ev);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  if (!on_device) {
+    e = hipMemcpyAsync(x, F.xhost, xelems * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+  }
+  e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->kt_fwd = ms * 1e-3;
+  if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->kt_diag = ms * 1e-3;
+  if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->kt_bwd = ms * 1e-3;
+  inform->time_solve = now() - t0;
+  inform->solve_bytes = 2 * 8 * S.num_factor + (h->posdef ? 0 : 16 * int64_t(S.n)) + 32 * int64_t(S.n);
+  return inform->flag;
+}
+
+int gsls_solve(void* handle, int32_t job, int32_t nrhs, double* x, int32_t ldx, const gsls_options*,
+               gsls_inform* inform) {
+  return solve_common(static_cast<Handle*>(handle), job, nrhs, x, ldx, false, inform);
+}
+
+int gsls_solve_dev(void* handle, int32_t job, int32_t nrhs, double* d_x, int32_t ldx,
+                   const gsls_options*, gsls_inform* inform) {
+  return solve_common(static_cast<Handle*>(handle), job, nrhs, d_x, ldx, true, inform);
+}
+
+// d[i] = diagonal of the Cholesky factor in pivot order (NumericSubtree.hxx:418-427)
+int gsls_enquire_posdef(void* handle, double* d, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->factored) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  if (!h->posdef) return inform->flag = GSLS_ERROR_NOT_LLT;
+  const Symbolic& S = h->S;
+  if (S.n == 0) return GSLS_SUCCESS;
+  DeviceGuard g(h->device);
+  std::vector<double> Lh(h->F.L_elems);
+  hipError_t e = hipMemcpy(Lh.data(), h->F.L, Lh.size() * sizeof(double), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  for (int s = 0; s < S.nnodes; ++s)
+    for (int j = 0; j < S.ncol(s); ++j) d[S.sptr[s] + j] = Lh[S.loff[s] + int64_t(j) * S.ldl[s] + j];
+  return GSLS_SUCCESS;
+}
+
+// piv_order[var] = +-(pivot position), d(2,n) inverted pivots in pivot order
+// (NumericSubtree.hxx:428-462, fkeep.F90:321-377)
+int gsls_enquire_indef(void* handle, int32_t* piv_order, double* d, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->factored) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  if (h->posdef) return inform->flag = GSLS_ERROR_NOT_LDLT;
+  const Symbolic& S = h->S;
+  if (S.n == 0) return GSLS_SUCCESS;
+  DeviceGuard g(h->device);
+  std::vector<double> Dh(2 * size_t(S.n));
+  hipError_t e = hipMemcpy(Dh.data(), h->F.D, Dh.size() * sizeof(double), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  for (int p = 0; p < S.n; ++p) {
+    const bool two_first = (p + 1 < S.n) && std::isinf(Dh[2 * size_t(p) + 2]);
+    const bool two_second = std::isinf(Dh[2 * size_t(p)]);
+    if (piv_order) piv_order[S.invp[p]] = (two_first || two_second) ? -(p + 1) : (p + 1);
+    if (d) {
+      d[2 * size_t(p)] = two_second ? Dh[2 * size_t(p) + 1] : Dh[2 * size_t(p)];
+      d[2 * size_t(p) + 1] = two_first ? Dh[2 * size_t(p) + 1] : 0.0;
+    }
+  }
+  return GSLS_SUCCESS;
+}
+
+int gsls_alter(void* handle, const double* d, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->factored) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  if (h->posdef) return inform->flag = GSLS_ERROR_NOT_LDLT;
+  const Symbolic& S = h->S;
+  if (S.n == 0) return GSLS_SUCCESS;
+  DeviceGuard g(h->device);
+  hipError_t e = hipMemcpy(h->F.D, d, 2 * size_t(S.n) * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  return GSLS_SUCCESS;
+}
+
+int gsls_get_symbolic_sizes(void* handle, int32_t* nnodes, int64_t* rlist_len, int64_t* nlist_len) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
+  if (nnodes) *nnodes = h->S.nnodes;
+  if (rlist_len) *rlist_len = h->S.nnodes ? h->S.rptr[h->S.nnodes] : 0;
+  if (nlist_len) *nlist_len = h->S.nnodes ? h->S.nptr[h->S.nnodes] : 0;
+  return GSLS_SUCCESS;
+}
+
+int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rptr, int32_t* rlist,
+                      int64_t* nptr, int64_t* nlist) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
+  const Symbolic& S = h->S;
+  const int nn = S.nnodes;
+  if (nn == 0) return GSLS_SUCCESS;
+  if (sptr) for (int i = 0; i <= nn; ++i) sptr[i] = S.sptr[i] + 1;
+  if (sparent) for (int i = 0; i < nn; ++i) sparent[i] = S.sparent[i] + 1;
+  if (rptr) for (int i = 0; i <= nn; ++i) rptr[i] = S.rptr[i] + 1;
+  if (rlist) for (int64_t i = 0; i < S.rptr[nn]; ++i) rlist[i] = S.rlist[i] + 1;
+  if (nptr) for (int i = 0; i <= nn; ++i) nptr[i] = S.nptr[i] + 1;
+  if (nlist) for (int64_t i = 0; i < 2 * S.nptr[nn]; ++i) nlist[i] = S.nlist[i] + 1;
+  return GSLS_SUCCESS;
+}
+
+void* gsls_get_stream(void* handle) {
+  Handle* h = static_cast<Handle*>(handle);
+  return h ? static_cast<void*>(h->stream) : nullptr;
+}
+
+int gsls_last_solve_kernel_seconds(void* handle, double* fwd, double* diag, double* bwd) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return GSLS_ERROR_CALL_SEQUENCE;
+  if (fwd) *fwd = h->kt_fwd;
+  if (diag) *diag = h->kt_diag;
+  if (bwd) *bwd = h->kt_bwd;
+  return GSLS_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,710 @@
+// HIP kernels and launch sequences of the gsls backend -- gfx950 (MI355X, CDNA4) only.
+//
+// What runs here replaces, behaviourally, the reference's numeric phase:
+//   * A -> front scatter           (ssids/cpu/kernels/assemble.hxx:49-79 add_a_block;
+//                                   CUDA: ssids/assemble.cu:39-96 cu_load_nodes[_sc])
+//   * child -> parent extend-add   (assemble.hxx:91-137, 244-345, 347-437; CUDA assemble.cu:170-230)
+//   * dense partial factorization  (ssids/cpu/kernels/cholesky.cxx:32-188; ldlt_app.cxx; CUDA
+//                                   dense_factor.cu cu_block_chol / cu_block_ldlt + syrk.cu)
+//   * contribution block           (factor.hxx:84-99 calcLD + gemm; CUDA syrk.cu:178-385)
+//   * forward / diagonal / backward solves (NumericSubtree.hxx:280-400; CUDA solve.cu, dtrsv.h)
+// but is organised MI355X-first: a level-set schedule over the assembly tree fixed at analyse time,
+// every level = a handful of batched launches over device-resident task lists, fronts resident in
+// HBM for the lifetime of the handle, 64-wide wavefronts, LDS-resident panels, and
+// v_mfma_f64_16x16x4_f64 for every L*D*L^T update.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+
+#include "gsls_device.hpp"
+
+namespace gsls {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define HIPCHK(call)                    \
+  do {                                  \
+    hipError_t e__ = (call);            \
+    if (e__ != hipSuccess) return e__;  \
+  } while (0)
+
+// =================================================================================================
+// A -> L scatter
+// =================================================================================================
+__global__ void k_scatter_a(int64_t cnt, const int64_t* __restrict__ asrc,
+                            const int64_t* __restrict__ adst, const double* __restrict__ val,
+                            double* __restrict__ L, const double* __restrict__ scale,
+                            const int32_t* __restrict__ arow, const int32_t* __restrict__ acol,
+                            const int32_t* __restrict__ invp) {
+  int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (; i < cnt; i += stride) {
+    double v = val[asrc[i]];
+    if (scale) v *= scale[invp[arow[i]]] * scale[invp[acol[i]]];
+    L[adst[i]] = v;
+  }
+}
+
+// =================================================================================================
+// extend-add: every parent pulls its children's contribution blocks, one child after the other
+// (deterministic summation order, no atomics).  One workgroup per parent.
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_assemble(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ asmnodes,
+           const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
+           double* __restrict__ L, double* __restrict__ C) {
+  const int p = asmnodes[blockIdx.x];
+  const NodeDesc P = nodes[p];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pcm = P.m - P.n;
+  for (int ci = P.cbeg; ci < P.cend; ++ci) {
+    const NodeDesc Cn = nodes[clist[ci]];
+    const int cm = Cn.m - Cn.n;
+    if (cm > 0) {
+      const int32_t* map = cmap + Cn.moff;
+      const double* src = C + Cn.coff;
+      for (int j = wave; j < cm; j += 4) {
+        const int pc = map[j];
+        double* dst = (pc < P.n) ? (L + P.loff + int64_t(pc) * P.ld)
+                                 : (C + P.coff + int64_t(pc - P.n) * pcm - P.n);
+        const double* s = src + int64_t(j) * cm;
+        for (int i = j + lane; i < cm; i += 64) dst[map[i]] += s[i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =================================================================================================
+// MFMA core:  acc(ARxBC tile) += Arows(:,k0:k1) * diag(d) * Brows(:,k0:k1)^T
+// A and B are row ranges of the same column-major L block.  v_mfma_f64_16x16x4_f64: lane l feeds
+// A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; result reg r of lane l is C[row=(l>>4)+4r][col=l&15].
+// =================================================================================================
+constexpr int KC = 16;
+
+template <int AROWS>
+struct Stage {
+  static constexpr int AST = AROWS + 16;  // == 16 mod 32 doubles: the two 16-lane halves of a
+  static constexpr int BST = 64 + 16;     // ds_read_b64 lane group land on disjoint banks
+  double As[KC][AST];
+  double Bs[KC][BST];
+};
+
+// MT x NT 16x16 tiles per wave at (rbase, cbase) of the staged panels
+template <int AROWS, int MT, int NT>
+__device__ __forceinline__ void mfma_panel(const Stage<AROWS>& sg, int rbase, int cbase, int lane,
+                                           double4_t (&acc)[MT][NT]) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int k4 = 0; k4 < KC; k4 += 4) {
+    double a[MT], b[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[i] = sg.As[k4 + lk][rbase + 16 * i + lr];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = sg.Bs[k4 + lk][cbase + 16 * j + lr];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// stage rows [arow0, arow0+AROWS) (valid < amax) and rows [brow0, brow0+64) (valid < bmax) of
+// columns [k0, k0+KC) (valid < kmax) of the front at Lb; B is scaled by d_k = 1/dinv[2k] if dinv.
+template <int AROWS>
+__device__ __forceinline__ void stage_panels(Stage<AROWS>& sg, const double* __restrict__ Lb, int ld,
+                                             int arow0, int amax, int brow0, int bmax, int k0,
+                                             int kmax, const double* __restrict__ dinv, int tid) {
+  for (int e = tid; e < AROWS * KC; e += 256) {
+    const int r = e % AROWS, kk = e / AROWS;
+    const int gr = arow0 + r, gk = k0 + kk;
+    sg.As[kk][r] = (gr < amax && gk < kmax) ? Lb[int64_t(gk) * ld + gr] : 0.0;
+  }
+  for (int e = tid; e < 64 * KC; e += 256) {
+    const int r = e & 63, kk = e >> 6;
+    const int gr = brow0 + r, gk = k0 + kk;
+    double v = (gr < bmax && gk < kmax) ? Lb[int64_t(gk) * ld + gr] : 0.0;
+    if (dinv && gk < kmax) {
+      const double di = dinv[2 * gk];
+      v = (di != 0.0) ? v / di : 0.0;
+    }
+    sg.Bs[kk][r] = v;
+  }
+}
+
+// =================================================================================================
+// diag kernel: block column `step` of a front: rows [kb, kb+128) x cols [kb, kb+w)
+//   1. left-looking update with the front's earlier block columns (MFMA)
+//   2. right-looking factorization of the 128 x w panel in LDS (Cholesky, or LDL^T with 1x1 pivots)
+//   3. store L11 (lower), the first row chunk of L21, and D^-1
+// stat[0]: smallest failing pivot position (posdef), stat[1]: #zero pivots, stat[2]: #negative
+// =================================================================================================
+constexpr int PR = 128;  // panel rows handled by the diag kernel
+constexpr int LDP = PR;  // LDS panel leading dimension
+
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_diag(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
+       double* __restrict__ L, double* __restrict__ D, int32_t* __restrict__ stat, double small) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
+  double* P = reinterpret_cast<double*>(smem_raw);  // overlays the staging buffers after the GEMM
+  __shared__ double dg[NB];
+
+  const PanelTask t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kb = t.step * NB;
+  const int w = min(NB, nd.n - kb);
+  const int pr = min(PR, nd.m - kb);
+  double* Lb = L + nd.loff;
+  const double* dinv = POSDEF ? nullptr : (D + 2 * int64_t(nd.sptr));
+
+  // ---- 1. acc = L[rows, 0:kb] * D * L[kb:kb+w, 0:kb]^T ------------------------------------------
+  double4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < kb; k0 += KC) {
+    __syncthreads();
+    stage_panels<PR>(sg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0, kb, dinv, tid);
+    __syncthreads();
+    mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
+  }
+  __syncthreads();
+  // ---- panel = A - acc, into LDS ------------------------------------------------------------------
+  {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * wave + 16 * i + lq + 4 * r;
+          const int col = 16 * j + lr;
+          double v = 0.0;
+          if (row < pr && col < w) v = Lb[int64_t(kb + col) * nd.ld + kb + row] - acc[i][j][r];
+          P[col * LDP + row] = v;
+        }
+  }
+  __syncthreads();
+
+  // ---- 2. right-looking factorization -----------------------------------------------------------
+  const int r = tid & (PR - 1), kofs = tid >> 7;
+  bool failed = false;
+  for (int j = 0; j < w; ++j) {
+    const double d = P[j * LDP + j];
+    double dinv_j, cscale;
+    if (POSDEF) {
+      if (!(d > 0.0)) {
+        if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + j);
+        failed = true;
+      }
+      dinv_j = 1.0 / d;
+      cscale = 1.0 / sqrt(d);
+    } else {
+      const bool zero = !(fabs(d) >= small);
+      dinv_j = zero ? 0.0 : 1.0 / d;
+      cscale = dinv_j;
+      if (tid == 0) {
+        if (zero) atomicAdd(&stat[1], 1);
+        else if (d < 0.0) atomicAdd(&stat[2], 1);
+      }
+    }
+    const double ar = (r > j && r < pr) ? P[j * LDP + r] : 0.0;
+    const double lr_ = ar * dinv_j;
+    for (int k = j + 1 + kofs; k < w; k += 2)
+      if (r >= k && r < pr) P[k * LDP + r] -= lr_ * P[j * LDP + k];
+    __syncthreads();
+    if (kofs == 0) {
+      if (r > j && r < pr) P[j * LDP + r] = ar * cscale;
+      if (r == j) dg[j] = POSDEF ? sqrt(d) : dinv_j;
+    }
+    __syncthreads();
+  }
+
+  // ---- 3. store ------------------------------------------------------------------------------------
+  for (int e = tid; e < pr * w; e += 256) {
+    const int row = e % pr, col = e / pr;
+    if (row > col)
+      Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row];
+    else if (row == col)
+      Lb[int64_t(kb + col) * nd.ld + kb + row] = POSDEF ? dg[col] : 1.0;
+  }
+  if (!POSDEF && tid < w) {
+    D[2 * int64_t(nd.sptr + kb + tid)] = dg[tid];
+    D[2 * int64_t(nd.sptr + kb + tid) + 1] = 0.0;
+  }
+}
+
+// =================================================================================================
+// panel kernel: row chunk c>=1 of block column `step`:  rows [kb+128+(c-1)*64, +64)
+//   R = (A - L[rows,0:kb] D L[kb:kb+w,0:kb]^T) * L11^-T * D11^-1
+// =================================================================================================
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
+        double* __restrict__ L, const double* __restrict__ D) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
+  double* Pc = reinterpret_cast<double*>(smem_raw);                  // [w][RB]
+  double* L11 = reinterpret_cast<double*>(smem_raw) + NB * RB;       // [w][NB] column-major
+  __shared__ double dsc[NB];
+
+  const PanelTask t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kb = t.step * NB;
+  const int w = min(NB, nd.n - kb);
+  const int r0 = kb + PR + (t.chunk - 1) * RB;
+  const int rows = min(RB, nd.m - r0);
+  double* Lb = L + nd.loff;
+  const double* dinv = POSDEF ? nullptr : (D + 2 * int64_t(nd.sptr));
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
+  for (int k0 = 0; k0 < kb; k0 += KC) {
+    __syncthreads();
+    stage_panels<RB>(sg, Lb, nd.ld, r0, nd.m, kb, kb + w, k0, kb, dinv, tid);
+    __syncthreads();
+    mfma_panel<RB, 2, 2>(sg, wr, wc, lane, acc);
+  }
+  __syncthreads();
+  {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr + 16 * i + lq + 4 * r;
+          const int col = wc + 16 * j + lr;
+          double v = 0.0;
+          if (row < rows && col < w) v = Lb[int64_t(kb + col) * nd.ld + r0 + row] - acc[i][j][r];
+          Pc[col * RB + row] = v;
+        }
+  }
+  for (int e = tid; e < w * w; e += 256) {
+    const int row = e % w, col = e / w;
+    L11[col * NB + row] = (row >= col) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
+  }
+  if (tid < w) dsc[tid] = POSDEF ? 1.0 / Lb[int64_t(kb + tid) * nd.ld + kb + tid] : dinv[2 * (kb + tid)];
+  __syncthreads();
+
+  // right-looking triangular solve, one barrier per column; finished columns go straight to HBM
+  const int r = tid & (RB - 1), kofs = tid >> 6;
+  for (int j = 0; j < w; ++j) {
+    const double a = Pc[j * RB + r];
+    const double x = POSDEF ? a * dsc[j] : a;  // posdef: l = a / l_jj ; indef: keep a = l * d_j
+    for (int k = j + 1 + kofs; k < w; k += 4) Pc[k * RB + r] -= x * L11[j * NB + k];
+    if (kofs == 0 && r < rows) Lb[int64_t(kb + j) * nd.ld + r0 + r] = POSDEF ? x : a * dsc[j];
+    __syncthreads();
+  }
+}
+
+// =================================================================================================
+// contribution kernel: tile (ti,tj) of  C -= L21 * D * L21^T   (K = n, MFMA)
+// =================================================================================================
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks,
+          const double* __restrict__ L, const double* __restrict__ D, double* __restrict__ C) {
+  __shared__ Stage<TS> sg;
+  const TileTask t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cm = nd.m - nd.n;
+  const double* Lb = L + nd.loff;
+  const double* dinv = POSDEF ? nullptr : (D + 2 * int64_t(nd.sptr));
+  const int ar0 = nd.n + t.ti * TS, br0 = nd.n + t.tj * TS;
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
+  for (int k0 = 0; k0 < nd.n; k0 += KC) {
+    __syncthreads();
+    stage_panels<TS>(sg, Lb, nd.ld, ar0, nd.m, br0, nd.m, k0, nd.n, dinv, tid);
+    __syncthreads();
+    mfma_panel<TS, 2, 2>(sg, wr, wc, lane, acc);
+  }
+  double* Cb = C + nd.coff;
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = t.ti * TS + wr + 16 * i + lq + 4 * r;
+        const int col = t.tj * TS + wc + 16 * j + lr;
+        if (row < cm && col < cm && row >= col) Cb[int64_t(col) * cm + row] -= acc[i][j][r];
+      }
+}
+
+// =================================================================================================
+// Solve kernels (v0: one workgroup per front, level by level)
+// =================================================================================================
+__global__ void k_permute_in(int n, const int32_t* __restrict__ invp, const double* __restrict__ x,
+                             const double* __restrict__ scale, double* __restrict__ xp) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int v = invp[i];
+    xp[i] = scale ? x[v] * scale[v] : x[v];
+  }
+}
+__global__ void k_permute_out(int n, const int32_t* __restrict__ invp, const double* __restrict__ xp,
+                              const double* __restrict__ scale, double* __restrict__ x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int v = invp[i];
+    x[v] = scale ? xp[i] * scale[v] : xp[i];
+  }
+}
+
+// forward substitution on one front: gather children's contribution vectors, solve L11 y = rhs,
+// leave my contribution vector cvec = (children pass-through) - L21 y
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
+            const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
+            const double* __restrict__ L, double* __restrict__ xp, double* __restrict__ cvec) {
+  extern __shared__ __attribute__((aligned(16))) double y[];  // n entries
+  const NodeDesc nd = nodes[lvl[blockIdx.x]];
+  const int tid = threadIdx.x;
+  const int n = nd.n, cm = nd.m - nd.n;
+  const double* Lb = L + nd.loff;
+  double* mine = cvec + nd.moff;
+  for (int i = tid; i < n; i += 256) y[i] = xp[nd.sptr + i];
+  for (int i = tid; i < cm; i += 256) mine[i] = 0.0;
+  __syncthreads();
+  for (int ci = nd.cbeg; ci < nd.cend; ++ci) {
+    const NodeDesc cn = nodes[clist[ci]];
+    const int ccm = cn.m - cn.n;
+    const int32_t* map = cmap + cn.moff;
+    const double* cv = cvec + cn.moff;
+    for (int i = tid; i < ccm; i += 256) {
+      const int idx = map[i];
+      if (idx < n) y[idx] += cv[i];
+      else mine[idx - n] += cv[i];
+    }
+    __syncthreads();
+  }
+  // column-oriented forward substitution
+  for (int k = 0; k < n; ++k) {
+    const double* col = Lb + int64_t(k) * nd.ld;
+    double yk = y[k];
+    if (POSDEF) yk /= col[k];
+    __syncthreads();
+    if (tid == 0) y[k] = yk;
+    for (int i = k + 1 + tid; i < n; i += 256) y[i] -= col[i] * yk;
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 256) xp[nd.sptr + i] = y[i];
+  // cvec -= L21 * y : one thread per row, columns streamed (coalesced across threads)
+  for (int i = tid; i < cm; i += 256) {
+    double s = 0.0;
+    const double* row = Lb + n + i;
+    for (int k = 0; k < n; ++k) s += row[int64_t(k) * nd.ld] * y[k];
+    mine[i] -= s;
+  }
+}
+
+__global__ void k_solve_diag(int n, const double* __restrict__ D, double* __restrict__ xp) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // D holds inverted pivots; 2x2 blocks are flagged by +inf in d[2i+2] (v0 produces 1x1 only)
+  xp[i] *= D[2 * int64_t(i)];
+}
+
+// backward substitution on one front: y = L11^-T (x1 - L21^T x2)
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
+            const int32_t* __restrict__ rlist, const double* __restrict__ L,
+            double* __restrict__ xp) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const NodeDesc nd = nodes[lvl[blockIdx.x]];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = nd.n, cm = nd.m - nd.n;
+  double* y = sh;       // n
+  double* z = sh + n;   // cm
+  const double* Lb = L + nd.loff;
+  const int32_t* rl = rlist + nd.roff + n;
+  for (int i = tid; i < n; i += 256) y[i] = xp[nd.sptr + i];
+  for (int i = tid; i < cm; i += 256) z[i] = xp[rl[i]];
+  __syncthreads();
+  // y[k] -= sum_i L21[i,k] z[i] : one wave per column, shuffle reduction
+  for (int k = wave; k < n; k += 4) {
+    const double* col = Lb + int64_t(k) * nd.ld + n;
+    double s = 0.0;
+    for (int i = lane; i < cm; i += 64) s += col[i] * z[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) y[k] -= s;
+  }
+  __syncthreads();
+  // L11^T y = rhs, dot-product form, columns of L11 are rows of L11^T (contiguous)
+  if (wave == 0) {
+    for (int k = n - 1; k >= 0; --k) {
+      const double* col = Lb + int64_t(k) * nd.ld;
+      double s = 0.0;
+      for (int i = k + 1 + lane; i < n; i += 64) s += col[i] * y[i];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+      if (lane == 0) {
+        double v = y[k] - s;
+        if (POSDEF) v /= col[k];
+        y[k] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) xp[nd.sptr + i] = y[i];
+}
+
+// =================================================================================================
+// host side: upload of the symbolic data and the per-level launch plan
+// =================================================================================================
+template <class T>
+static hipError_t upload(T*& dptr, const std::vector<T>& h, hipStream_t st) {
+  dptr = nullptr;
+  if (h.empty()) return hipSuccess;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&dptr), h.size() * sizeof(T)));
+  return hipMemcpyAsync(dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+}
+
+void dev_free(DeviceFactor& F) {
+  void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
+                  F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
+                  F.xhost, F.stat};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  F = DeviceFactor();
+}
+
+hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st) {
+  dev_free(F);
+  const int nn = S.nnodes;
+  std::vector<NodeDesc> nd(nn);
+  for (int s = 0; s < nn; ++s) {
+    NodeDesc& d = nd[s];
+    d.m = S.nrow(s);
+    d.n = S.ncol(s);
+    d.ld = S.ldl[s];
+    d.sptr = S.sptr[s];
+    d.cbeg = S.cptr[s];
+    d.cend = S.cptr[s + 1];
+    d.parent = S.sparent[s];
+    d.pad = 0;
+    d.loff = S.loff[s];
+    d.coff = S.coff[s];
+    d.roff = S.rptr[s];
+    d.moff = S.cmapptr[s];
+  }
+  // A -> L scatter lists with absolute destinations
+  const int64_t nz = S.nptr[nn];
+  std::vector<int64_t> asrc(nz), adst(nz);
+  std::vector<int32_t> arow(nz), acol(nz);
+  for (int s = 0; s < nn; ++s) {
+    const int64_t m = S.nrow(s);
+    for (int64_t k = S.nptr[s]; k < S.nptr[s + 1]; ++k) {
+      const int64_t dst = S.nlist[2 * k + 1];
+      const int64_t c = dst / m, r = dst % m;
+      asrc[k] = S.nlist[2 * k];
+      adst[k] = S.loff[s] + c * S.ldl[s] + r;
+      arow[k] = S.rlist[S.rptr[s] + r];
+      acol[k] = S.sptr[s] + int(c);
+    }
+  }
+  // launch plan
+  std::vector<PanelTask> pt;
+  std::vector<TileTask> tt;
+  std::vector<int32_t> asmn;
+  F.plan.assign(S.nlevels, LevelPlan());
+  for (int l = 0; l < S.nlevels; ++l) {
+    LevelPlan& lp = F.plan[l];
+    lp.node_begin = S.lvlptr[l];
+    lp.node_end = S.lvlptr[l + 1];
+    int maxsteps = 0;
+    for (int i = lp.node_begin; i < lp.node_end; ++i)
+      maxsteps = std::max(maxsteps, (S.ncol(S.lvlnodes[i]) + NB - 1) / NB);
+    // per step: diag tasks first, then the extra row chunks
+    lp.panel_begin.assign(2 * maxsteps, 0);
+    lp.panel_cnt.assign(2 * maxsteps, 0);
+    for (int st_ = 0; st_ < maxsteps; ++st_) {
+      lp.panel_begin[2 * st_] = int(pt.size());
+      for (int i = lp.node_begin; i < lp.node_end; ++i) {
+        const int s = S.lvlnodes[i];
+        if (S.ncol(s) > st_ * NB) pt.push_back(PanelTask{s, st_, 0, 0});
+      }
+      lp.panel_cnt[2 * st_] = int(pt.size()) - lp.panel_begin[2 * st_];
+      lp.panel_begin[2 * st_ + 1] = int(pt.size());
+      for (int i = lp.node_begin; i < lp.node_end; ++i) {
+        const int s = S.lvlnodes[i];
+        if (S.ncol(s) <= st_ * NB) continue;
+        const int rem = S.nrow(s) - st_ * NB - PR;
+        for (int c = 1; (c - 1) * RB < rem; ++c) pt.push_back(PanelTask{s, st_, c, 0});
+      }
+      lp.panel_cnt[2 * st_ + 1] = int(pt.size()) - lp.panel_begin[2 * st_ + 1];
+    }
+    lp.tile_begin = int(tt.size());
+    for (int i = lp.node_begin; i < lp.node_end; ++i) {
+      const int s = S.lvlnodes[i];
+      if (S.sparent[s] >= nn) continue;  // roots have no (used) contribution block
+      const int cm = S.nrow(s) - S.ncol(s);
+      const int nt = (cm + TS - 1) / TS;
+      for (int tj = 0; tj < nt; ++tj)
+        for (int ti = tj; ti < nt; ++ti) tt.push_back(TileTask{s, ti, tj, 0});
+    }
+    lp.tile_cnt = int(tt.size()) - lp.tile_begin;
+    lp.asm_begin = int(asmn.size());
+    for (int i = lp.node_begin; i < lp.node_end; ++i) {
+      const int s = S.lvlnodes[i];
+      if (S.cptr[s + 1] > S.cptr[s]) asmn.push_back(s);
+    }
+    lp.asm_cnt = int(asmn.size()) - lp.asm_begin;
+  }
+
+  HIPCHK(upload(F.nodes, nd, st));
+  HIPCHK(upload(F.rlist, S.rlist, st));
+  HIPCHK(upload(F.cmap, S.cmap, st));
+  HIPCHK(upload(F.clist, S.clist, st));
+  HIPCHK(upload(F.lvlnodes, S.lvlnodes, st));
+  HIPCHK(upload(F.asmnodes, asmn, st));
+  HIPCHK(upload(F.asrc, asrc, st));
+  HIPCHK(upload(F.adst, adst, st));
+  HIPCHK(upload(F.arow, arow, st));
+  HIPCHK(upload(F.acol, acol, st));
+  HIPCHK(upload(F.ptasks, pt, st));
+  HIPCHK(upload(F.ttasks, tt, st));
+  HIPCHK(upload(F.invp, S.invp, st));
+  F.nscatter = nz;
+  F.L_elems = S.loff[nn];
+  F.C_elems = S.coff[nn];
+  F.cvec_elems = S.cmapptr[nn];
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.L), std::max<int64_t>(F.L_elems, 1) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.C), std::max<int64_t>(F.C_elems, 1) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.D), std::max<int64_t>(2 * int64_t(S.n), 2) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), std::max<int64_t>(F.cvec_elems, 1) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), 16 * sizeof(int32_t)));
+  HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  return hipSuccess;
+}
+
+// -------------------------------------------------------------------------------------------------
+template <bool POSDEF>
+static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small, hipStream_t st) {
+  const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * PR * NB);
+  const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RB + NB * NB));
+  for (int l = 0; l < S.nlevels; ++l) {
+    const LevelPlan& lp = F.plan[l];
+    if (lp.asm_cnt > 0)
+      hipLaunchKernelGGL(k_assemble, dim3(lp.asm_cnt), dim3(256), 0, st, F.nodes,
+                         F.asmnodes + lp.asm_begin, F.clist, F.cmap, F.L, F.C);
+    const int nsteps = int(lp.panel_cnt.size() / 2);
+    for (int s = 0; s < nsteps; ++s) {
+      if (lp.panel_cnt[2 * s] > 0)
+        hipLaunchKernelGGL(k_diag<POSDEF>, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st,
+                           F.nodes, F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.stat, small);
+      if (lp.panel_cnt[2 * s + 1] > 0)
+        hipLaunchKernelGGL(k_panel<POSDEF>, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_panel, st,
+                           F.nodes, F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D);
+    }
+    if (lp.tile_cnt > 0)
+      hipLaunchKernelGGL(k_contrib<POSDEF>, dim3(lp.tile_cnt), dim3(256), 0, st, F.nodes,
+                         F.ttasks + lp.tile_begin, F.L, F.D, F.C);
+  }
+  return hipGetLastError();
+}
+
+hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
+                      const double* d_scale, double small, hipStream_t st) {
+  HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(F.D, 0, std::max<int64_t>(2 * int64_t(S.n), 2) * sizeof(double), st));
+  const int32_t init[16] = {INT_MAX, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(F.stat, init, sizeof(init), hipMemcpyHostToDevice, st));
+  if (F.nscatter > 0) {
+    const int blocks = int(std::min<int64_t>((F.nscatter + 255) / 256, 256 * 8));
+    hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, F.nscatter, F.asrc, F.adst, d_val,
+                       F.L, d_scale, F.arow, F.acol, F.invp);
+  }
+  if (posdef) return factor_levels<true>(S, F, small, st);
+  return factor_levels<false>(S, F, small, st);
+}
+
+template <bool POSDEF>
+static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, double* xp, hipStream_t st,
+                               hipEvent_t* ev) {
+  const bool do_fwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
+  const bool do_diag = !POSDEF && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_DIAG ||
+                                   job == GSLS_SOLVE_JOB_DIAG_BWD);
+  const bool do_bwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD ||
+                       job == GSLS_SOLVE_JOB_DIAG_BWD);
+  if (ev) HIPCHK(hipEventRecord(ev[0], st));
+  if (do_fwd)
+    for (int l = 0; l < S.nlevels; ++l) {
+      const LevelPlan& lp = F.plan[l];
+      int maxn = 0;
+      for (int i = lp.node_begin; i < lp.node_end; ++i) maxn = std::max(maxn, S.ncol(S.lvlnodes[i]));
+      hipLaunchKernelGGL(k_solve_fwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
+                         sizeof(double) * std::max(maxn, 1), st, F.nodes, F.lvlnodes + lp.node_begin,
+                         F.clist, F.cmap, F.L, xp, F.cvec);
+    }
+  if (ev) HIPCHK(hipEventRecord(ev[1], st));
+  if (do_diag)
+    hipLaunchKernelGGL(k_solve_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, xp);
+  if (ev) HIPCHK(hipEventRecord(ev[2], st));
+  if (do_bwd)
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+      const LevelPlan& lp = F.plan[l];
+      int maxm = 0;
+      for (int i = lp.node_begin; i < lp.node_end; ++i) maxm = std::max(maxm, S.nrow(S.lvlnodes[i]));
+      hipLaunchKernelGGL(k_solve_bwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
+                         sizeof(double) * std::max(maxm, 1), st, F.nodes, F.lvlnodes + lp.node_begin,
+                         F.rlist, F.L, xp);
+    }
+  if (ev) HIPCHK(hipEventRecord(ev[3], st));
+  return hipGetLastError();
+}
+
+hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
+                     int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev) {
+  if (F.nrhs_cap < 1) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), std::max(S.n, 1) * sizeof(double)));
+    F.nrhs_cap = 1;
+  }
+  const int blocks = (S.n + 255) / 256;
+  // which side of the permutation/scaling each job touches (fkeep.F90:229-318)
+  for (int r = 0; r < nrhs; ++r) {
+    double* x = d_x + int64_t(r) * ldx;
+    if (S.n == 0) continue;
+    const bool scale_in = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
+    const bool scale_out = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD ||
+                                       job == GSLS_SOLVE_JOB_DIAG_BWD);
+    hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
+                       scale_in ? d_scale : nullptr, F.xp);
+    hipError_t e = posdef ? solve_sweeps<true>(S, F, job, F.xp, st, (r == 0) ? ev : nullptr)
+                          : solve_sweeps<false>(S, F, job, F.xp, st, (r == 0) ? ev : nullptr);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.xp,
+                       scale_out ? d_scale : nullptr, x);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gsls

@@ -1,0 +1,84 @@
+// Device-side data layout and launcher prototypes of the gsls backend (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "gsls_internal.hpp"
+
+namespace gsls {
+
+constexpr int NB = 64;   // block-column width of the panel factorization
+constexpr int RB = 64;   // row-chunk height handled by one workgroup
+constexpr int TS = 64;   // contribution-block tile edge
+
+// One front.  L block: m x n column-major, leading dimension ld, at L + loff.
+// Contribution block: (m-n) x (m-n) column-major (lower triangle meaningful) at C + coff.
+struct NodeDesc {
+  int32_t m, n, ld, sptr;      // sptr = first pivot position of the node
+  int32_t cbeg, cend;          // children in clist[cbeg..cend)
+  int32_t parent, pad;
+  int64_t loff, coff;
+  int64_t roff;                // offset of the node's row list in rlist
+  int64_t moff;                // offset of the node's (m-n) child->parent map / contribution vector
+};
+
+// unit of work of the panel kernel: block column `step` of node `node`, row chunk `chunk`
+struct PanelTask {
+  int32_t node, step, chunk, pad;
+};
+// unit of work of the contribution kernel: tile (ti,tj), ti>=tj, of node's contribution block
+struct TileTask {
+  int32_t node, ti, tj, pad;
+};
+
+struct LevelPlan {
+  int node_begin, node_end;                 // range in lvlnodes
+  std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
+  int tile_begin, tile_cnt;                 // range in the TileTask array
+  int asm_begin, asm_cnt;                   // parents with children: range in asm node list
+};
+
+struct DeviceFactor {
+  // symbolic (uploaded once per analyse)
+  NodeDesc* nodes = nullptr;
+  int32_t* rlist = nullptr;
+  int32_t* cmap = nullptr;
+  int32_t* clist = nullptr;
+  int32_t* lvlnodes = nullptr;
+  int32_t* asmnodes = nullptr;
+  int64_t* asrc = nullptr;     // A -> L scatter: source index in val
+  int64_t* adst = nullptr;     //                 destination element in L
+  int32_t* arow = nullptr;     // pivot positions (row, col) of each scattered entry, for scaling
+  int32_t* acol = nullptr;
+  PanelTask* ptasks = nullptr;
+  TileTask* ttasks = nullptr;
+  int32_t* invp = nullptr;     // position -> variable
+  int64_t nscatter = 0;
+  std::vector<LevelPlan> plan;
+  // numeric
+  double* L = nullptr;
+  double* C = nullptr;         // contribution arena
+  double* D = nullptr;         // 2*n inverted pivots in pivot order (indefinite)
+  double* val = nullptr;       // staging for host-supplied values
+  double* scale = nullptr;     // staging for host-supplied scaling (variable order)
+  double* xp = nullptr;        // permuted solution / rhs workspace (n * nrhs_cap)
+  double* cvec = nullptr;      // per-node contribution vectors for the forward solve
+  double* xhost = nullptr;     // staging for host x
+  int32_t* stat = nullptr;     // [0] first failing pivot position+1 (posdef) / flag, [1] zero pivots,
+                               // [2] num_neg, [3] num_two, [4] delays
+  int64_t L_elems = 0, C_elems = 0, cvec_elems = 0;
+  int nrhs_cap = 0;
+  int64_t val_cap = 0;
+};
+
+// ---- launchers (gsls_device.hip) -----------------------------------------------------------------
+hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st);
+void dev_free(DeviceFactor& F);
+hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
+                      const double* d_scale, double small, hipStream_t st);
+hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
+                     int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);
+
+}  // namespace gsls

@@ -1,0 +1,438 @@
+// Symbolic analysis for the gsls backend: elimination tree, postorder, column counts, relaxed
+// supernodes, row lists, A->front map, plus the level-set schedule the HIP kernels run.
+//
+// The numbers this produces (nnodes, sptr, sparent, rptr, rlist, nptr/nlist, num_factor,
+// num_flops, final order) must equal the reference's for the same (pattern, order, nemin), because
+// SLS surfaces them (inform%entries_in_factors / flops_elimination, src/sls/sls.f90:1758-1759) and
+// bench.py prices throughput with them.  The behaviour followed is that of
+//   src/spral/core_analyse.f90:38-151   basic_analyse (driver)
+//   :173-223   Liu's elimination tree with path compression
+//   :233-352   postorder (children ascending, structurally empty columns last)
+//   :387-521   Gilbert/Ng/Peyton column counts
+//   :536-853   relaxed supernodes: merge child into parent when no fill is added or both are
+//              narrower than nemin; children visited widest-first
+//   :911-998   row lists, :1007-1064 sort, :862-902 statistics
+//   src/ssids/anal.f90:1129-1231  build_map (A entry -> position in front)
+//   src/ssids/anal.f90:37-80      expand_pattern, :147-197 check_order
+// It is written from that behaviour, 0-based, on std::vector; integer-only, O(nnz alpha(n)).
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "gsls_internal.hpp"
+
+namespace gsls {
+namespace {
+
+// full symmetric pattern (both triangles) from the lower triangle by columns
+void expand_lower(int n, const int64_t* ptr, const int32_t* row, std::vector<int64_t>& aptr,
+                  std::vector<int>& arow) {
+  aptr.assign(n + 1, 0);
+  for (int j = 0; j < n; ++j)
+    for (int64_t k = ptr[j] - 1; k < ptr[j + 1] - 1; ++k) {
+      int i = row[k] - 1;
+      aptr[i + 1]++;
+      if (i != j) aptr[j + 1]++;
+    }
+  for (int j = 0; j < n; ++j) aptr[j + 1] += aptr[j];
+  arow.resize(aptr[n]);
+  std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
+  for (int j = 0; j < n; ++j)
+    for (int64_t k = ptr[j] - 1; k < ptr[j + 1] - 1; ++k) {
+      int i = row[k] - 1;
+      arow[fill[i]++] = j;
+      if (i != j) arow[fill[j]++] = i;
+    }
+}
+
+// parent[p] for pivot positions p (n = virtual root)
+void elimination_tree(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow,
+                      const std::vector<int>& perm, const std::vector<int>& invp,
+                      std::vector<int>& parent) {
+  parent.assign(n, n);
+  std::vector<int> anc(n, n);  // compressed path to the current top of each partial tree
+  for (int p = 0; p < n; ++p) {
+    int c = invp[p];
+    for (int64_t k = aptr[c]; k < aptr[c + 1]; ++k) {
+      int j = perm[arow[k]];
+      if (j >= p) continue;
+      while (anc[j] < p) {
+        int nxt = anc[j];
+        anc[j] = p;
+        j = nxt;
+      }
+      if (anc[j] == p) continue;  // already hangs below p
+      parent[j] = p;
+      anc[j] = p;
+    }
+  }
+}
+
+// Relabel pivots in depth-first order: every parent directly after its last child's subtree,
+// children kept in ascending order, structurally empty roots moved to the very end.
+void postorder(int n, const std::vector<int64_t>& aptr, std::vector<int>& perm,
+               std::vector<int>& invp, std::vector<int>& parent, int& realn) {
+  std::vector<int> head(n + 1, -1), next(n + 1, -1);
+  for (int i = n - 1; i >= 0; --i) {
+    next[i] = head[parent[i]];
+    head[parent[i]] = i;
+  }
+  std::vector<int> relabel(n + 1), stack;
+  stack.reserve(n + 1);
+  realn = n;
+  int id = n;
+  stack.push_back(n);
+  while (!stack.empty()) {
+    int v = stack.back();
+    stack.pop_back();
+    relabel[v] = id--;
+    if (v == n) {
+      for (int c = head[v]; c != -1; c = next[c])
+        if (aptr[invp[c] + 1] != aptr[invp[c]]) stack.push_back(c);
+      for (int c = head[v]; c != -1; c = next[c])
+        if (aptr[invp[c] + 1] == aptr[invp[c]]) {
+          --realn;
+          stack.push_back(c);
+        }
+    } else {
+      for (int c = head[v]; c != -1; c = next[c]) stack.push_back(c);
+    }
+  }
+  std::vector<int> old_invp(invp), old_parent(parent);
+  for (int i = 0; i < n; ++i) invp[relabel[i]] = old_invp[i];
+  for (int i = 0; i < n; ++i) perm[invp[i]] = i;
+  for (int i = 0; i < n; ++i) parent[relabel[i]] = relabel[old_parent[i]];
+}
+
+int find_top(std::vector<int>& up, int u) {
+  int root = u;
+  while (up[root] != -1) root = up[root];
+  while (up[u] != -1) {  // full path compression
+    int nxt = up[u];
+    if (nxt != root) up[u] = root;
+    u = nxt;
+  }
+  return root;
+}
+
+// cc[p] = number of entries (diagonal included) in column p of L
+void column_counts(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow,
+                   const std::vector<int>& perm, const std::vector<int>& invp,
+                   const std::vector<int>& parent, std::vector<int>& cc) {
+  std::vector<int> first(n + 1);
+  std::iota(first.begin(), first.end(), 0);
+  cc.assign(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    int p = parent[i];
+    first[p] = std::min(first[p], first[i]);
+    cc[i] = (first[i] == i) ? 1 : 0;
+  }
+  std::vector<int> up(n + 1, -1), last_piv(n + 1, -1), last_nbr(n + 1, -1);
+  for (int p = 0; p < n; ++p) {
+    int c = invp[p];
+    for (int64_t k = aptr[c]; k < aptr[c + 1]; ++k) {
+      int u = perm[arow[k]];
+      if (u <= p) continue;
+      if (first[p] > last_nbr[u]) {
+        cc[p]++;
+        int q = last_piv[u];
+        if (q != -1) cc[find_top(up, q)]--;
+        last_piv[u] = p;
+      }
+      last_nbr[u] = p;
+    }
+    int par = parent[p];
+    cc[par] += cc[p] - 1;
+    up[p] = par;
+  }
+}
+
+struct Supernodes {
+  int nnodes = 0;
+  std::vector<int> sperm;  // old pivot position -> new pivot position
+  std::vector<int> sptr, sparent, scc;
+};
+
+void relaxed_supernodes(int n, int realn, const std::vector<int>& parent,
+                        const std::vector<int>& cc, int nemin, Supernodes& out) {
+  const int64_t kNever = INT64_MAX;
+  std::vector<int> nelim(n + 1, 1), nvert(n + 1, 1), mhead(n + 1, -1), mnext(n + 1, -1);
+  std::vector<int64_t> ezero(n + 1, 0);
+  std::vector<char> keep(n + 1, 0);
+  ezero[n] = kNever;
+  nelim[n] = n + 1 + nemin;
+
+  std::vector<int> head(n + 1, -1), next(n + 1, -1);
+  for (int i = realn - 1; i >= 0; --i) {
+    next[i] = head[parent[i]];
+    head[parent[i]] = i;
+  }
+  std::vector<int> kids;
+  for (int par = 0; par <= n; ++par) {
+    kids.clear();
+    for (int c = head[par]; c != -1; c = next[c]) kids.push_back(c);
+    std::stable_sort(kids.begin(), kids.end(), [&](int a, int b) { return cc[a] > cc[b]; });
+    for (int c : kids) {
+      bool merge = false;
+      if (ezero[par] != kNever)
+        merge = (cc[par] == cc[c] - 1 && nelim[par] == 1) || (nelim[par] < nemin && nelim[c] < nemin);
+      if (merge) {
+        mnext[c] = mhead[par];
+        mhead[par] = c;
+        ezero[par] += ezero[c] + (int64_t(cc[par]) - 1 + nelim[par] - cc[c] + 1) * nelim[par];
+        nelim[par] += nelim[c];
+        nvert[par] += nvert[c];
+      } else {
+        keep[c] = 1;
+      }
+    }
+  }
+
+  out.sperm.assign(n, 0);
+  out.sptr.clear();
+  out.scc.clear();
+  std::vector<int> owner(n + 1, 0), vpar;
+  std::vector<int> stack;
+  int v = 0, nn = 0;
+  for (int node = 0; node < realn; ++node) {
+    if (!keep[node]) continue;
+    out.sptr.push_back(v);
+    vpar.push_back(parent[node]);
+    out.scc.push_back(cc[node] + nelim[node] - 1);
+    v += nvert[node];
+    int k = v;
+    stack.assign(1, node);
+    while (!stack.empty()) {
+      int i = stack.back();
+      stack.pop_back();
+      out.sperm[i] = --k;
+      owner[i] = nn;
+      if (mnext[i] != -1) stack.push_back(mnext[i]);
+      if (mhead[i] != -1) stack.push_back(mhead[i]);
+    }
+    ++nn;
+  }
+  out.sptr.push_back(v);
+  out.nnodes = nn;
+  owner[n] = nn;
+  for (int i = realn; i < n; ++i) out.sperm[i] = i;
+  out.sparent.resize(nn);
+  for (int s = 0; s < nn; ++s) out.sparent[s] = owner[vpar[s]];
+}
+
+}  // namespace
+
+int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* order, int ordering,
+                     int nemin, Symbolic& S) {
+  S = Symbolic();
+  S.n = n;
+  if (nemin < 1) nemin = 32;
+  int flag = GSLS_SUCCESS;
+
+  std::vector<int64_t> aptr;
+  std::vector<int> arow;
+  expand_lower(n, ptr, row, aptr, arow);
+
+  // ---- pivot order ---------------------------------------------------------------------------
+  S.perm.assign(n, 0);
+  S.invp.assign(n, -1);
+  if (ordering == GSLS_ORDER_USER) {
+    if (!order) return GSLS_ERROR_ORDER;
+    for (int i = 0; i < n; ++i) {
+      int j = order[i] < 0 ? -order[i] : order[i];
+      if (j < 1 || j > n || S.invp[j - 1] != -1) return GSLS_ERROR_ORDER;
+      S.invp[j - 1] = i;
+      S.perm[i] = j - 1;
+    }
+  } else {
+    if (ordering == GSLS_ORDER_NATURAL)
+      std::iota(S.perm.begin(), S.perm.end(), 0);
+    else
+      order_nested_dissection(n, aptr, arow, S.perm);
+    for (int i = 0; i < n; ++i) S.invp[S.perm[i]] = i;
+  }
+
+  // ---- tree, counts, supernodes -----------------------------------------------------------------
+  std::vector<int> parent, cc;
+  elimination_tree(n, aptr, arow, S.perm, S.invp, parent);
+  postorder(n, aptr, S.perm, S.invp, parent, S.realn);
+  if (S.realn != n) flag = GSLS_WARNING_ANAL_SINGULAR;
+  column_counts(n, aptr, arow, S.perm, S.invp, parent, cc);
+  Supernodes sn;
+  relaxed_supernodes(n, S.realn, parent, cc, nemin, sn);
+
+  // final pivot order = supernode renumbering applied on top of the postorder
+  {
+    std::vector<int> old_invp(S.invp);
+    for (int i = 0; i < n; ++i) S.invp[sn.sperm[i]] = old_invp[i];
+    for (int i = 0; i < n; ++i) S.perm[S.invp[i]] = i;
+  }
+  S.nnodes = sn.nnodes;
+  S.sptr = sn.sptr;
+  S.sparent = sn.sparent;
+  const int nn = S.nnodes;
+
+  // ---- row lists: own pivots + what the children pass up + new rows from A, then sorted ---------
+  S.rptr.assign(nn + 1, 0);
+  for (int s = 0; s < nn; ++s) S.rptr[s + 1] = S.rptr[s] + sn.scc[s];
+  S.rlist.assign(S.rptr[nn], 0);
+  S.cptr.assign(nn + 2, 0);
+  for (int s = 0; s < nn; ++s) S.cptr[S.sparent[s] + 1]++;
+  for (int s = 0; s <= nn; ++s) S.cptr[s + 1] += S.cptr[s];
+  S.clist.resize(nn);
+  {
+    std::vector<int> fill(S.cptr.begin(), S.cptr.end() - 1);
+    for (int s = 0; s < nn; ++s) S.clist[fill[S.sparent[s]]++] = s;
+  }
+  {
+    std::vector<int> seen(n, -1);
+    for (int s = 0; s < nn; ++s) {
+      int64_t w = S.rptr[s];
+      for (int p = S.sptr[s]; p < S.sptr[s + 1]; ++p) {
+        seen[p] = s;
+        S.rlist[w++] = p;
+      }
+      for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
+        int c = S.clist[ci];
+        for (int64_t k = S.rptr[c]; k < S.rptr[c + 1]; ++k) {
+          int j = S.rlist[k];
+          if (j < S.sptr[s] || seen[j] == s) continue;
+          seen[j] = s;
+          S.rlist[w++] = j;
+        }
+      }
+      for (int p = S.sptr[s]; p < S.sptr[s + 1]; ++p) {
+        int c = S.invp[p];
+        for (int64_t k = aptr[c]; k < aptr[c + 1]; ++k) {
+          int j = S.perm[arow[k]];
+          if (j < p || seen[j] == s) continue;
+          seen[j] = s;
+          S.rlist[w++] = j;
+        }
+      }
+      if (w != S.rptr[s + 1]) return GSLS_ERROR_UNKNOWN;  // column counts and pattern disagree
+      std::sort(S.rlist.begin() + S.rptr[s], S.rlist.begin() + S.rptr[s + 1]);
+    }
+  }
+
+  // ---- statistics (core_analyse.f90:862-902) ----------------------------------------------------
+  S.num_factor = 0;
+  S.num_flops = 0;
+  for (int s = 0; s < nn; ++s) {
+    int64_t ne = S.ncol(s), m = S.nrow(s) - ne;
+    S.num_factor += ne * (ne + 1) / 2 + ne * m;
+    for (int64_t j = 1; j <= ne; ++j) S.num_flops += (m + j) * (m + j);
+  }
+
+  // ---- user-visible order: 0 for variables that are never eliminated ---------------------------
+  if (order) {
+    for (int i = 0; i < n; ++i) order[i] = S.perm[i] + 1;
+    for (int p = S.sptr[nn]; p < n; ++p) order[S.invp[p]] = 0;
+  }
+
+  // ---- A -> front map (anal.f90:1129-1231): entries of row `col` left of the diagonal first (in
+  //      column order), then the entries of column `col` itself ------------------------------------
+  {
+    const int64_t nz = ptr[n] - 1;
+    std::vector<int64_t> tptr(n + 1, 0), origin(nz);
+    std::vector<int> tcol(nz);
+    for (int j = 0; j < n; ++j)
+      for (int64_t k = ptr[j] - 1; k < ptr[j + 1] - 1; ++k)
+        if (row[k] - 1 != j) tptr[row[k]]++;
+    for (int j = 0; j < n; ++j) tptr[j + 1] += tptr[j];
+    {
+      std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+      for (int j = 0; j < n; ++j)
+        for (int64_t k = ptr[j] - 1; k < ptr[j + 1] - 1; ++k) {
+          int i = row[k] - 1;
+          if (i == j) continue;
+          tcol[fill[i]] = j;
+          origin[fill[i]++] = k;
+        }
+    }
+    S.nptr.assign(nn + 1, 0);
+    S.nlist.clear();
+    S.nlist.reserve(2 * nz);
+    std::vector<int> local(n, 0);
+    for (int s = 0; s < nn; ++s) {
+      S.nptr[s] = int64_t(S.nlist.size() / 2);
+      const int64_t m = S.nrow(s);
+      for (int64_t k = S.rptr[s]; k < S.rptr[s + 1]; ++k) local[S.rlist[k]] = int(k - S.rptr[s]);
+      for (int p = S.sptr[s]; p < S.sptr[s + 1]; ++p) {
+        int c = S.invp[p];
+        for (int64_t k = tptr[c]; k < tptr[c + 1]; ++k) {
+          int r = S.perm[tcol[k]];
+          if (r < p) continue;
+          S.nlist.push_back(origin[k]);
+          S.nlist.push_back(int64_t(p - S.sptr[s]) * m + local[r]);
+        }
+      }
+      for (int p = S.sptr[s]; p < S.sptr[s + 1]; ++p) {
+        int c = S.invp[p];
+        for (int64_t k = ptr[c] - 1; k < ptr[c + 1] - 1; ++k) {
+          int r = S.perm[row[k] - 1];
+          if (r < p) continue;
+          S.nlist.push_back(k);
+          S.nlist.push_back(int64_t(p - S.sptr[s]) * m + local[r]);
+        }
+      }
+    }
+    S.nptr[nn] = int64_t(S.nlist.size() / 2);
+  }
+
+  // ---- tree statistics (anal.f90:1093-1106) -----------------------------------------------------
+  {
+    std::vector<int> depth(nn + 1, 0);
+    S.maxfront = 0;
+    S.maxdepth = 0;
+    for (int s = nn - 1; s >= 0; --s) {
+      depth[s] = depth[S.sparent[s]] + 1;
+      S.maxfront = std::max(S.maxfront, S.ncol(s));
+      S.maxdepth = std::max(S.maxdepth, depth[s]);
+    }
+  }
+
+  // ---- level-set schedule + child->parent row maps + storage layout (ours) ----------------------
+  S.level.assign(nn + 1, 0);
+  for (int s = 0; s < nn; ++s) {
+    int p = S.sparent[s];
+    S.level[p] = std::max(S.level[p], S.level[s] + 1);
+  }
+  S.nlevels = 0;
+  for (int s = 0; s < nn; ++s) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
+  S.lvlptr.assign(S.nlevels + 1, 0);
+  for (int s = 0; s < nn; ++s) S.lvlptr[S.level[s] + 1]++;
+  for (int l = 0; l < S.nlevels; ++l) S.lvlptr[l + 1] += S.lvlptr[l];
+  S.lvlnodes.resize(nn);
+  {
+    std::vector<int> fill(S.lvlptr.begin(), S.lvlptr.end() - 1);
+    for (int s = 0; s < nn; ++s) S.lvlnodes[fill[S.level[s]]++] = s;
+  }
+  S.cmapptr.assign(nn + 1, 0);
+  for (int s = 0; s < nn; ++s) S.cmapptr[s + 1] = S.cmapptr[s] + (S.nrow(s) - S.ncol(s));
+  S.cmap.assign(S.cmapptr[nn], -1);
+  for (int s = 0; s < nn; ++s) {
+    int p = S.sparent[s];
+    if (p >= nn) continue;
+    int64_t a = S.rptr[s] + S.ncol(s), ae = S.rptr[s + 1];
+    int64_t b = S.rptr[p], be = S.rptr[p + 1];
+    int64_t w = S.cmapptr[s];
+    for (; a < ae; ++a) {
+      while (b < be && S.rlist[b] < S.rlist[a]) ++b;
+      if (b == be || S.rlist[b] != S.rlist[a]) return GSLS_ERROR_UNKNOWN;  // child row not in parent
+      S.cmap[w++] = int(b - S.rptr[p]);
+    }
+  }
+  S.loff.assign(nn + 1, 0);
+  S.coff.assign(nn + 1, 0);
+  S.ldl.assign(nn, 0);
+  for (int s = 0; s < nn; ++s) {
+    int64_t m = S.nrow(s), ne = S.ncol(s);
+    S.ldl[s] = align_ld(int(m));
+    S.loff[s + 1] = S.loff[s] + int64_t(S.ldl[s]) * ne;
+    S.coff[s + 1] = S.coff[s] + (m - ne) * (m - ne);
+  }
+  return flag;
+}
+
+}  // namespace gsls

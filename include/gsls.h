@@ -1,0 +1,198 @@
+/*
+ * gsls.h -- C ABI of the MI355X-native sparse symmetric factorize+solve backend ("gsls") that
+ * drops in under GALAHAD's SLS / SBLS path.
+ *
+ * The boundary is modelled on the one the reference already has between SLS and its SSIDS backend:
+ * every entry point below names the reference interface it replaces (paths relative to the GALAHAD
+ * tree).  SLS reaches these through the ISO_C_BINDING module galahad_amd/fortran/gsls_iface.f90;
+ * INTEGRATION.md shows the `CASE ( 'gsls' )` arms a maintainer adds to src/sls/sls.f90.
+ *
+ * Conventions (same as src/ssids/ssids.f90):
+ *   - indices handed in are 1-based (Fortran); `ptr` is 64-bit, `row` is 32-bit;
+ *   - the matrix is the LOWER triangle by columns, every diagonal entry present, no duplicates
+ *     (SLS pre-sums duplicates and inserts diagonals, src/sls/sls.f90:8409-8578);
+ *   - x is column-major with leading dimension ldx >= n;
+ *   - D is returned INVERTED: d[2*i] diagonal, d[2*i+1] off-diagonal of a 2x2 (fkeep.F90:357-359);
+ *     piv_order[i] < 0 marks a member of a 2x2 pivot (fkeep.F90:353-356);
+ *   - every function returns the SSIDS flag space (src/ssids/datatypes.f90:25-59): 0 success,
+ *     < 0 error, > 0 warning; the same value is stored in inform->flag.  Nothing throws or aborts
+ *     across this ABI.
+ *   - caller owns ptr/row/val/x/order; the handle owns symbolic data, factors and device memory.
+ *
+ * There is NO CPU fallback behind this ABI: without a usable HIP device gsls_analyse keeps working
+ * (it is host integer work) but gsls_factor / gsls_solve return GSLS_ERROR_HIP (-51).
+ */
+#ifndef GSLS_H
+#define GSLS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- flags: identical values to src/ssids/datatypes.f90:25-59 ---------------------------------- */
+enum {
+  GSLS_SUCCESS = 0,
+  GSLS_ERROR_CALL_SEQUENCE = -1,
+  GSLS_ERROR_A_N_OOR = -2,
+  GSLS_ERROR_A_PTR = -3,
+  GSLS_ERROR_A_ALL_OOR = -4,
+  GSLS_ERROR_SINGULAR = -5,
+  GSLS_ERROR_NOT_POS_DEF = -6,
+  GSLS_ERROR_PTR_ROW = -7,
+  GSLS_ERROR_ORDER = -8,
+  GSLS_ERROR_VAL = -9,
+  GSLS_ERROR_X_SIZE = -10,
+  GSLS_ERROR_JOB_OOR = -11,
+  GSLS_ERROR_NOT_LLT = -13,
+  GSLS_ERROR_NOT_LDLT = -14,
+  GSLS_ERROR_ALLOCATION = -50,
+  GSLS_ERROR_HIP = -51,           /* SSIDS_ERROR_CUDA_UNKNOWN */
+  GSLS_ERROR_UNIMPLEMENTED = -98,
+  GSLS_ERROR_UNKNOWN = -99,
+  GSLS_WARNING_ANAL_SINGULAR = 6,
+  GSLS_WARNING_FACT_SINGULAR = 7
+};
+
+/* solve jobs: src/ssids/datatypes.f90:61-66 */
+enum {
+  GSLS_SOLVE_JOB_ALL = 0,      /* P L D (P L)^T x = b */
+  GSLS_SOLVE_JOB_FWD = 1,      /* P L x = b           */
+  GSLS_SOLVE_JOB_DIAG = 2,     /* D x = b  (indefinite only) */
+  GSLS_SOLVE_JOB_BWD = 3,      /* (P L)^T x = b       */
+  GSLS_SOLVE_JOB_DIAG_BWD = 4  /* D (P L)^T x = b     */
+};
+
+/* ordering choices for gsls_options.ordering */
+enum {
+  GSLS_ORDER_USER = 0,     /* `order` supplied by the caller (ssids ordering=0)            */
+  GSLS_ORDER_ND = 1,       /* built-in nested dissection (stands where ssids calls METIS)   */
+  GSLS_ORDER_NATURAL = 3   /* identity                                                      */
+};
+
+/* Mirrors the fields of type(ssids_options) that SLS sets (src/sls/sls.f90:1385-1439,
+ * src/ssids/datatypes.f90:187-283).  Plain ints/doubles only, so the Fortran bind(C) type is 1:1. */
+typedef struct gsls_options {
+  int32_t print_level;     /* <0 silent (default -1)                                            */
+  int32_t ordering;        /* GSLS_ORDER_*                                                      */
+  int32_t nemin;           /* supernode amalgamation, default 32 (core_analyse.f90:806-822)      */
+  int32_t scaling;         /* 0 none / user supplied `scale`                                     */
+  int32_t action;          /* indefinite: continue on singularity with warning 7 (default 1)     */
+  int32_t device;          /* HIP device ordinal, -1 = current device                            */
+  int32_t use_graph;       /* replay the factorization as a captured hipGraph (default 1)        */
+  int32_t reserved0;
+  double u;                /* relative pivot threshold, default 0.01                             */
+  double small;            /* absolute pivot tolerance, default 1e-20                            */
+  double multiplier;       /* factor-memory head-room for delayed pivots, default 1.1            */
+  double reserved1;
+} gsls_options;
+
+/* Mirrors type(ssids_inform) (src/ssids/inform.f90:17-44) + phase timings that SLS copies into
+ * inform%time%*_external (src/sls/sls.f90:363-429). */
+typedef struct gsls_inform {
+  int32_t flag;
+  int32_t matrix_dup;
+  int32_t matrix_missing_diag;
+  int32_t matrix_outrange;
+  int32_t matrix_rank;
+  int32_t maxdepth;
+  int32_t maxfront;
+  int32_t num_delay;
+  int64_t num_factor;
+  int64_t num_flops;
+  int32_t num_neg;
+  int32_t num_sup;
+  int32_t num_two;
+  int32_t stat;
+  int32_t hip_error;       /* hipError_t of the failing runtime call, 0 otherwise                */
+  int32_t not_first_pass;
+  int32_t nlevels;         /* depth of the level-set schedule                                    */
+  int32_t reserved0;
+  int64_t factor_bytes;    /* device bytes held by L, D                                          */
+  int64_t solve_bytes;     /* algorithmic bytes of one fwd+diag+bwd solve, one rhs               */
+  double time_analyse;     /* seconds, wall                                                      */
+  double time_factor;
+  double time_solve;
+  double reserved1;
+} gsls_inform;
+
+/* ---- lifecycle ----------------------------------------------------------------------------------- */
+
+/* default options (type(ssids_options) initialisers, datatypes.f90:187-283) */
+void gsls_default_options(gsls_options* options);
+
+/* allocate an empty handle; replaces the akeep/fkeep pair SLS embeds (sls.f90:793-796) */
+int gsls_create(void** handle);
+
+/* replaces ssids_free(akeep, fkeep, cuda_error)  src/ssids/ssids.f90:1388-1419 */
+int gsls_destroy(void** handle);
+
+/* ---- analyse ------------------------------------------------------------------------------------- */
+
+/* replaces ssids_analyse(check=.false., n, ptr, row, akeep, options, inform, order)
+ *          src/ssids/ssids.f90:148-392  (called from SLS_analyse, src/sls/sls.f90:3115-3150).
+ * order[n]: in: position of variable i in the pivot sequence (1-based) when ordering==GSLS_ORDER_USER;
+ *           out: the pivot order actually used (ssids.f90:381). */
+int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row, int32_t* order,
+                 const gsls_options* options, gsls_inform* inform);
+
+/* ---- factorize ----------------------------------------------------------------------------------- */
+
+/* replaces ssids_factor(posdef, val, akeep, fkeep, options, inform [, scale], ptr, row)
+ *          src/ssids/ssids.f90:770-1108 (called from SLS_factorize, src/sls/sls.f90:4273-4297).
+ * val[ptr[n]-1]: lower-triangle values in the order of `row` given to gsls_analyse (host memory).
+ * scale: NULL, or n user scaling factors applied as S A S. */
+int gsls_factor(void* handle, int32_t posdef, const double* val, const double* scale,
+                const gsls_options* options, gsls_inform* inform);
+
+/* same, with `val` (and `scale`) already resident in HBM (device pointers); asynchronous on the
+ * handle's stream apart from the final status read-back. */
+int gsls_factor_dev(void* handle, int32_t posdef, const double* d_val, const double* d_scale,
+                    const gsls_options* options, gsls_inform* inform);
+
+/* ---- solve --------------------------------------------------------------------------------------- */
+
+/* replaces ssids_solve(x, ...) / ssids_solve(nrhs, x, ldx, ..., job)
+ *          src/ssids/ssids.f90:1114-1249 (called from SLS_solve_one_rhs / SLS_solve_multiple_rhs,
+ *          src/sls/sls.f90:5392-5397, 5693-5700; SLS_part_solve, sls.f90:6886-6920). */
+int gsls_solve(void* handle, int32_t job, int32_t nrhs, double* x, int32_t ldx,
+               const gsls_options* options, gsls_inform* inform);
+
+/* same with x resident in HBM */
+int gsls_solve_dev(void* handle, int32_t job, int32_t nrhs, double* d_x, int32_t ldx,
+                   const gsls_options* options, gsls_inform* inform);
+
+/* ---- enquire / alter ----------------------------------------------------------------------------- */
+
+/* replaces ssids_enquire_posdef(akeep, fkeep, options, inform, d)  src/ssids/ssids.f90:1255-1293 */
+int gsls_enquire_posdef(void* handle, double* d, gsls_inform* inform);
+
+/* replaces ssids_enquire_indef(akeep, fkeep, options, inform, piv_order, d)  ssids.f90:1299-1341;
+ * either output may be NULL. d is (2,n) column-major. */
+int gsls_enquire_indef(void* handle, int32_t* piv_order, double* d, gsls_inform* inform);
+
+/* replaces ssids_alter(d, akeep, fkeep, options, inform)  src/ssids/ssids.f90:1347-1384 */
+int gsls_alter(void* handle, const double* d, gsls_inform* inform);
+
+/* ---- introspection used by the parity tests and bench (not part of the SSIDS surface) ------------ */
+
+/* symbolic factorization as the reference's akeep holds it (src/ssids/akeep.f90:25-76):
+ * sizes first (any output pointer may be NULL), then the arrays, 1-based like the reference. */
+int gsls_get_symbolic_sizes(void* handle, int32_t* nnodes, int64_t* rlist_len, int64_t* nlist_len);
+int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rptr, int32_t* rlist,
+                      int64_t* nptr, int64_t* nlist);
+
+/* stream the handle launches on (hipStream_t as void*), and per-phase kernel timing of the last
+ * solve measured with HIP events on that stream (seconds); used by bench.py's roofline block. */
+void* gsls_get_stream(void* handle);
+int gsls_last_solve_kernel_seconds(void* handle, double* fwd, double* diag, double* bwd);
+
+/* library/device probe: returns number of visible HIP devices (0 when none / no driver) */
+int gsls_device_count(void);
+const char* gsls_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSLS_H */
