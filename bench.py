@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- SLS factorize+solve throughput of the gsls (MI355X) backend.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
+  * workload (N=1): BASELINE.json configs[1] -- banded SPD, n = 1e5, semi-bandwidth 127, fp64,
+    generator tests/problems.py:banded_spd (seed 20240101).
+  * one step  = SLS_factorize + SLS_solve of that system through the C ABI (gsls_factor_dev +
+    gsls_solve_dev): matrix values and right-hand side are resident in HBM when the clock starts.
+    Analyse (symbolic, host integer work) is outside the metric, as in the reference's own timers
+    (inform%time%clock_factorize / clock_solve, src/sls/sls.f90:4676-4683, 4951-4958).
+  * value     = N * K * F / t, F = the reference's flops_elimination for this matrix in its natural
+    order (2 065 810 544) -- the same numerator for the CPU and the GPU rows,
+    whatever ordering the GPU run chose, so reordering can never inflate the number.
+  * N > 1     = N independent systems, one per rank (the path does not shard a chain-structured
+    band across devices: "replicas only"); time = max over ranks.
+  * roofline  = triangular-solve sweep against HBM: algorithmic bytes of one solve
+    (2*8*nnz(L) + 4*8*n, SURVEY.md section 8d, with nnz(L) of the ordering actually used)
+    / HIP-event time of the sweep's kernels on the library's stream.
+  * cpu_baseline = the real reference (oracle/_ref/ref_driver: GALAHAD SLS + SPRAL SSIDS CPU,
+    vendored reference BLAS) on the same matrix, natural order, all host cores; rank 0, N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+F_NATURAL_CFG2 = 2065810544  # reference flops_elimination, cfg2, natural order
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100000)
+    ap.add_argument("--semibw", type=int, default=127)
+    ap.add_argument("--ordering", choices=["free", "natural"], default="free",
+                    help="free: the backend's own ordering (perf run); natural: identity PERM (parity run)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(prob, threads):
+    """reference Fortran CPU path on the same matrix (natural order), bounded: 1 warm-up + 3 repeats"""
+    from oracle import refio
+    if not refio.available():
+        return None
+    n, row, col, val, rhs, xs = prob
+    r = refio.run(n, row, col, val, rhs, perm=np.arange(1, n + 1), pivot_control=2, repeat=4,
+                  threads=threads, timeout=1200)
+    if r["status_factorize"] != 0 or r["status_solve"] != 0:
+        return None
+    t = r["t_factorize_median"] + r["t_solve_median"]
+    return {"value": r["flops_elimination"] / t / 1e9, "unit": "GF/s", "cores": threads,
+            "kind": "reference",
+            "sample": "full workload, PERM=identity, median of 4 SLS_factorize+SLS_solve (ssids, "
+                      "vendored reference BLAS): factorize %.3fs solve %.3fs analyse %.2fs" % (
+                          r["t_factorize_median"], r["t_solve_median"], r["t_analyse"]),
+            "flops_elimination": r["flops_elimination"], "max_err": float(np.abs(r["x"] - xs).max())}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    from galahad_amd import dist as gdist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import problems as P
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    from galahad_amd._lib import Inform, lib
+
+    # every rank owns one independent system of the same shape (different seed): weak scaling
+    prob = P.banded_spd(a.n, a.semibw, seed=20240101 + rank)
+    n, row, col, val, rhs, xs = prob
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s, c, inf = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, inf)
+    c.pivot_control = 2
+    s.opts.device = local_rank
+    if a.ordering == "natural":
+        c.ordering = 0
+    t0 = time.perf_counter()
+    s.analyse(m, c, inf)
+    t_analyse = time.perf_counter() - t0
+    assert inf.status == 0, inf.status
+    nnzL, flops_used = inf.entries_in_factors, inf.flops_elimination
+
+    # inputs resident in HBM before the clock starts
+    VAL = s.scatter_values(m)
+    d_val = torch.from_numpy(VAL).cuda()
+    d_rhs = torch.from_numpy(rhs).cuda()
+    d_x = torch.empty_like(d_rhs)
+    ginf = Inform()
+
+    def step():
+        f = lib.gsls_factor_dev(s.handle, 1, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts), C.byref(ginf))
+        assert f == 0, f
+        d_x.copy_(d_rhs)
+        torch.cuda.current_stream().synchronize()
+        f = lib.gsls_solve_dev(s.handle, 0, 1, C.c_void_p(d_x.data_ptr()), n, C.byref(s.opts), C.byref(ginf))
+        assert f == 0, f
+
+    for _ in range(a.warmup):
+        step()
+    gdist.barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ksolve = []
+    tf = ts = 0.0
+    for _ in range(a.steps):
+        step()
+        tf += ginf.time_factor if False else 0.0
+        kf, kd, kb = C.c_double(), C.c_double(), C.c_double()
+        lib.gsls_last_solve_kernel_seconds(s.handle, C.byref(kf), C.byref(kd), C.byref(kb))
+        ksolve.append(kf.value + kd.value + kb.value)
+    torch.cuda.synchronize()
+    gdist.barrier(world)
+    elapsed = gdist.max_over_ranks(time.perf_counter() - t0, world)
+
+    # correctness of what was timed
+    x = d_x.cpu().numpy()
+    res = P.scaled_residual(n, row, col, val, x, rhs)
+    assert res <= 1e-13, res
+
+    if rank == 0:
+        F = F_NATURAL_CFG2 if (a.n == 100000 and a.semibw == 127) else None
+        if F is None:
+            F = flops_used if a.ordering == "natural" else None
+        if F is None:   # non-default shape: natural-order flops from a second symbolic analyse
+            s2, c2, i2 = SLS(), Control(), InformSLS()
+            s2.initialize("gsls", c2, i2)
+            c2.ordering = 0
+            s2.analyse(m, c2, i2)
+            F = i2.flops_elimination
+            s2.terminate()
+        value = world * a.steps * F / elapsed / 1e9
+        solve_bytes = 2 * 8 * nnzL + 4 * 8 * n
+        t_sweep = float(np.mean(ksolve))
+        achieved = solve_bytes / t_sweep / 1e9
+        out = {
+            "metric": "SLS factorize+solve GF/s (fp64)", "value": value, "unit": "GF/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SLS standalone: random banded SPD n=%d, semi-bandwidth=%d, fp64 "
+                                   "(BASELINE.json configs[1]); one system per GPU" % (a.n, a.semibw),
+                       "ordering": a.ordering, "flops_numerator": F,
+                       "flops_executed_per_step": flops_used, "entries_in_factors": nnzL,
+                       "levels": inf.gsls_inform["nlevels"], "supernodes": inf.gsls_inform["num_sup"],
+                       "analyse_s": t_analyse, "scaled_residual": res},
+            "roofline": {"bound": "hbm", "kernel": "triangular solve sweep (fwd+diag+bwd kernels)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": solve_bytes, "seconds_per_launch": t_sweep},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            base_prob = P.banded_spd(a.n, a.semibw, seed=20240101)
+            cb = cpu_baseline(base_prob, threads=os.cpu_count() or 1)
+            if cb is not None:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    s.terminate()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

