@@ -49,22 +49,39 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(prob, threads):
-    """reference Fortran CPU path on the same matrix (natural order), bounded: 1 warm-up + 3 repeats"""
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(prob):
+    """reference Fortran CPU path on the same matrix (natural order), bounded: a few repeats at two
+    thread counts (the reference's OpenMP task code degrades badly when oversubscribed, so the best
+    of {8, min(cores,16)} threads is reported -- the count used is stated in `cores`)"""
     from oracle import refio
     if not refio.available():
         return None
     n, row, col, val, rhs, xs = prob
-    r = refio.run(n, row, col, val, rhs, perm=np.arange(1, n + 1), pivot_control=2, repeat=4,
-                  threads=threads, timeout=1200)
-    if r["status_factorize"] != 0 or r["status_solve"] != 0:
+    best = None
+    for threads in sorted({min(8, host_cores()), min(16, host_cores())}):
+        r = refio.run(n, row, col, val, rhs, perm=np.arange(1, n + 1), pivot_control=2, repeat=3,
+                      threads=threads, timeout=1200)
+        if r["status_factorize"] != 0 or r["status_solve"] != 0:
+            continue
+        t = r["t_factorize_median"] + r["t_solve_median"]
+        if best is None or t < best[0]:
+            best = (t, threads, r)
+    if best is None:
         return None
-    t = r["t_factorize_median"] + r["t_solve_median"]
+    t, threads, r = best
     return {"value": r["flops_elimination"] / t / 1e9, "unit": "GF/s", "cores": threads,
             "kind": "reference",
-            "sample": "full workload, PERM=identity, median of 4 SLS_factorize+SLS_solve (ssids, "
-                      "vendored reference BLAS): factorize %.3fs solve %.3fs analyse %.2fs" % (
-                          r["t_factorize_median"], r["t_solve_median"], r["t_analyse"]),
+            "sample": "full workload, PERM=identity, median of 3 SLS_factorize+SLS_solve (ssids, "
+                      "vendored reference BLAS, OMP_NUM_THREADS=%d of %d usable cores): factorize %.3fs "
+                      "solve %.3fs analyse %.2fs" % (threads, host_cores(), r["t_factorize_median"],
+                                                     r["t_solve_median"], r["t_analyse"]),
             "flops_elimination": r["flops_elimination"], "max_err": float(np.abs(r["x"] - xs).max())}
 
 
@@ -170,7 +187,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             base_prob = P.banded_spd(a.n, a.semibw, seed=20240101)
-            cb = cpu_baseline(base_prob, threads=os.cpu_count() or 1)
+            cb = cpu_baseline(base_prob)
             if cb is not None:
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

@@ -4,7 +4,7 @@ set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd)
 OUT=$HERE/../libgsls.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
+FLAGS="${GSLS_EXTRA:-} -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
 mkdir -p $HERE/obj
 pids=()
 for f in gsls_symbolic.cpp gsls_order.cpp gsls_api.cpp ; do

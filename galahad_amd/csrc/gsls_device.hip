@@ -25,6 +25,13 @@ namespace gsls {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+#ifdef GSLS_STAMPS   // diagnostic build only: in-kernel phase stamps (s_memtime), never in the product
+__device__ unsigned long long g_stamps[64];
+#define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 #define HIPCHK(call)                    \
   do {                                  \
     hipError_t e__ = (call);            \
@@ -55,12 +62,12 @@ __global__ void k_scatter_a(int64_t cnt, const int64_t* __restrict__ asrc,
 __global__ void __launch_bounds__(256)
 k_assemble(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ asmnodes,
            const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
-           double* __restrict__ L, double* __restrict__ C) {
+           double* __restrict__ L, double* __restrict__ C, int first_rank) {
   const int p = asmnodes[blockIdx.x];
   const NodeDesc P = nodes[p];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pcm = P.m - P.n;
-  for (int ci = P.cbeg; ci < P.cend; ++ci) {
+  for (int ci = P.cbeg + first_rank; ci < P.cend; ++ci) {
     const NodeDesc Cn = nodes[clist[ci]];
     const int cm = Cn.m - Cn.n;
     if (cm > 0) {
@@ -75,6 +82,40 @@ k_assemble(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ asmno
       }
     }
     __syncthreads();
+  }
+}
+
+// Tiled flavour for the first few children of every parent: one launch per child rank, so that the
+// children summed concurrently always belong to different parents (no atomics, fixed summation
+// order); a workgroup takes ACOLS columns of one child's contribution block.
+constexpr int ACOLS = 16;
+struct AsmTask {
+  int32_t child, col0;
+};
+__global__ void __launch_bounds__(256)
+k_assemble_tile(const NodeDesc* __restrict__ nodes, const AsmTask* __restrict__ tasks,
+                const int32_t* __restrict__ cmap, double* __restrict__ L, double* __restrict__ C) {
+  const AsmTask t = tasks[blockIdx.x];
+  const NodeDesc Cn = nodes[t.child];
+  const NodeDesc P = nodes[Cn.parent];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cm = Cn.m - Cn.n, pcm = P.m - P.n;
+  const int32_t* map = cmap + Cn.moff;
+  const double* src = C + Cn.coff;
+  const int jend = min(t.col0 + ACOLS, cm);
+  for (int j = t.col0 + wave; j < jend; j += 4) {
+    const int pc = map[j];
+    double* dst = (pc < P.n) ? (L + P.loff + int64_t(pc) * P.ld)
+                             : (C + P.coff + int64_t(pc - P.n) * pcm - P.n);
+    const double* sc = src + int64_t(j) * cm;
+    int i = j + lane;
+    for (; i + 192 < cm; i += 256) {   // four independent read-modify-writes in flight per lane
+      const int m0 = map[i], m1 = map[i + 64], m2 = map[i + 128], m3 = map[i + 192];
+      const double v0 = sc[i], v1 = sc[i + 64], v2 = sc[i + 128], v3 = sc[i + 192];
+      const double d0 = dst[m0], d1 = dst[m1], d2 = dst[m2], d3 = dst[m3];
+      dst[m0] = d0 + v0; dst[m1] = d1 + v1; dst[m2] = d2 + v2; dst[m3] = d3 + v3;
+    }
+    for (; i < cm; i += 64) dst[map[i]] += sc[i];
   }
 }
 
@@ -157,7 +198,7 @@ __device__ __forceinline__ void stage_panels(Stage<AROWS>& sg, const double* __r
 // stat[0]: smallest failing pivot position (posdef), stat[1]: #zero pivots, stat[2]: #negative
 // =================================================================================================
 constexpr int PR = 128;  // panel rows handled by the diag kernel
-constexpr int LDP = PR;  // LDS panel leading dimension
+constexpr int LDP = PR + 1;  // LDS panel leading dimension (odd: column-strided access is conflict free)
 
 // ---- Cholesky flavour ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -166,7 +207,6 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);  // overlays the staging buffers after the GEMM
-  __shared__ double dg[NB];
 
   const PanelTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
@@ -176,6 +216,7 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   const int pr = min(PR, nd.m - kb);
   double* Lb = L + nd.loff;
 
+  STAMP(0);
   double4_t acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -188,6 +229,7 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
   }
   __syncthreads();
+  STAMP(1);
   {
     const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
@@ -205,33 +247,53 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   }
   __syncthreads();
 
-  const int r = tid & (PR - 1), kofs = tid >> 7;
+  // ---- right-looking Cholesky of the 128 x w panel, register resident.  Thread (c, q) owns rows
+  // [32q, 32q+32) of column c, so every register index below is static while j stays a run-time
+  // loop (a fully unrolled 64-step body is ~125 KB of code and becomes instruction-fetch bound).
+  // Per eliminated column: its four owners publish it to LDS, one barrier, everybody applies the
+  // rank-1 update to its own column from LDS broadcasts.
+  STAMP(2);
+  const int c = tid & 63, q = tid >> 6;
+  double a[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) a[i] = P[c * LDP + 32 * q + i];
+  __syncthreads();
+  STAMP(3);
+  double* colbuf = P;            // 2 x PR doubles, double buffered (the panel now lives in registers)
   bool failed = false;
   for (int j = 0; j < w; ++j) {
-    const double d = P[j * LDP + j];
+    double* cb = colbuf + (j & 1) * PR;
+    if (c == j) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) cb[32 * q + i] = a[i];
+    }
+    __syncthreads();
+    const double d = cb[j];
     if (!(d > 0.0)) {
       if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + j);
       failed = true;
     }
-    const double dinv_j = 1.0 / d;
-    const double ar = (r > j && r < pr) ? P[j * LDP + r] : 0.0;
-    const double lr_ = ar * dinv_j;
-    for (int k = j + 1 + kofs; k < w; k += 2)
-      if (r >= k && r < pr) P[k * LDP + r] -= lr_ * P[j * LDP + k];
-    __syncthreads();
-    if (kofs == 0) {
-      if (r > j && r < pr) P[j * LDP + r] = ar / sqrt(d);
-      if (r == j) dg[j] = sqrt(d);
+    if (c > j) {
+      const double f = cb[c] / d;            // a(c,j) / d
+#pragma unroll
+      for (int i = 0; i < 32; ++i) a[i] -= cb[32 * q + i] * f;
+    } else if (c == j) {
+      const double s = sqrt(d), is = 1.0 / s;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) a[i] = (32 * q + i == j) ? s : a[i] * is;
     }
-    __syncthreads();
   }
+  __syncthreads();
+  STAMP(4);
+  // ---- back through LDS so that the store to HBM is coalesced along rows -----------------------------
+#pragma unroll
+  for (int i = 0; i < 32; ++i) P[c * LDP + 32 * q + i] = a[i];
+  __syncthreads();
   for (int e = tid; e < pr * w; e += 256) {
     const int row = e % pr, col = e / pr;
-    if (row > col)
-      Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row];
-    else if (row == col)
-      Lb[int64_t(kb + col) * nd.ld + kb + row] = dg[col];
+    if (row >= col) Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row];
   }
+  STAMP(5);
 }
 
 // ---- LDL^T flavour: complete pivoting (1x1 and 2x2) inside the w x w diagonal block, applied to the
@@ -472,6 +534,8 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 // panel kernel: row chunk c>=1 of block column `step`:  rows [kb+128+(c-1)*64, +64)
 //   R = (A - L[rows,0:kb] D L[kb:kb+w,0:kb]^T) * L11^-T * D11^-1
 // =================================================================================================
+constexpr int RBP = RB + 1;   // odd LDS stride: column-strided register loads are conflict free
+
 template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
@@ -479,8 +543,8 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         int32_t* __restrict__ stat, double u) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
-  double* Pc = reinterpret_cast<double*>(smem_raw);                  // [w][RB]
-  double* L11 = reinterpret_cast<double*>(smem_raw) + NB * RB;       // [w][NB] column-major
+  double* Pc = reinterpret_cast<double*>(smem_raw);                  // [w][RBP]
+  double* L11 = reinterpret_cast<double*>(smem_raw) + NB * RBP;      // [w][NB] column-major
   __shared__ double dsc[2 * NB + 4];
   __shared__ int32_t lp[NB];
 
@@ -520,7 +584,7 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
           const int col = wc + 16 * j + lr;
           double v = 0.0;   // the block's pivoting permuted its columns: gather column lp[col] of A
           if (row < rows && col < w) v = Lb[int64_t(kb + lp[col]) * nd.ld + r0 + row] - acc[i][j][r];
-          Pc[col * RB + row] = v;
+          Pc[col * RBP + row] = v;
         }
   }
   for (int e = tid; e < w * w; e += 256) {
@@ -534,35 +598,62 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
   }
   __syncthreads();
 
-  // right-looking substitution with the unit/non-unit L11, one barrier per column; finished
-  // columns are scaled by D^-1 (1x1 or 2x2) and go straight to HBM
-  const int r = tid & (RB - 1), kofs = tid >> 6;
+  // forward substitution against L11 (unit for LDL^T).  Thread (c, q) owns rows [16q, 16q+16) of
+  // column c in registers (static indices, run-time column loop); per column: its owners publish the
+  // finished (L D) column, one barrier, the columns to the right take their update.
   const double inv_u = (!POSDEF && u > 0.0) ? 1.0 / u : INFINITY;
   bool big = false;
-  for (int j = 0; j < w; ++j) {
-    const double a = Pc[j * RB + r];
-    const double x = POSDEF ? a * dsc[j] : a;  // posdef: l = a / l_jj ; indef: keep a = (L D)_j
-    for (int k = j + 1 + kofs; k < w; k += 4) Pc[k * RB + r] -= x * L11[j * NB + k];
-    if (kofs == 0 && r < rows) {
+  {
+    const int c = tid & 63, q = tid >> 6;
+    double a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = Pc[c * RBP + 16 * q + i];
+    __syncthreads();
+    double* xb = Pc;             // 2 x RB doubles, double buffered
+    for (int j = 0; j < w; ++j) {
+      double* cb = xb + (j & 1) * RB;
+      if (c == j) {
+        const double sc = POSDEF ? dsc[j] : 1.0;   // posdef: l = a / l_jj ; indef: keep a = (L D)_j
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          a[i] *= sc;
+          cb[16 * q + i] = a[i];
+        }
+      }
+      __syncthreads();
+      if (c > j && c < w) {
+        const double f = L11[j * NB + c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] -= cb[16 * q + i] * f;
+      }
+    }
+    __syncthreads();
+    // D^-1 scaling (1x1 / 2x2) needs the neighbouring column: go back through LDS
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Pc[c * RBP + 16 * q + i] = a[i];
+    __syncthreads();
+    for (int e = tid; e < rows * w; e += 256) {
+      const int r = e % rows, j = e / rows;
       double* out = Lb + int64_t(kb + j) * nd.ld + r0 + r;
+      const double aj = Pc[j * RBP + r];
       if (POSDEF) {
-        *out = x;
+        *out = aj;
       } else if (isinf(dsc[2 * j])) {
-        // second column of a 2x2 pivot: written together with the first
+        const double a1 = Pc[(j - 1) * RBP + r];
+        const double l2 = dsc[2 * j - 1] * a1 + dsc[2 * j + 1] * aj;
+        *out = l2;
+        if (fabs(l2) > inv_u) big = true;
       } else if (j + 1 < w && isinf(dsc[2 * j + 2])) {
-        const double a2 = Pc[(j + 1) * RB + r];   // l_{j+1,j} = 0, so already final
-        const double d11 = dsc[2 * j], d21 = dsc[2 * j + 1], d22 = dsc[2 * j + 3];
-        const double l1 = d11 * a + d21 * a2, l2 = d21 * a + d22 * a2;
-        out[0] = l1;
-        out[nd.ld] = l2;
-        if (fabs(l1) > inv_u || fabs(l2) > inv_u) big = true;
+        const double a2 = Pc[(j + 1) * RBP + r];
+        const double l1 = dsc[2 * j] * aj + dsc[2 * j + 1] * a2;
+        *out = l1;
+        if (fabs(l1) > inv_u) big = true;
       } else {
-        const double l = a * dsc[2 * j];
+        const double l = aj * dsc[2 * j];
         *out = l;
         if (fabs(l) > inv_u) big = true;
       }
     }
-    __syncthreads();
   }
   if (!POSDEF && __syncthreads_or(big) && tid == 0) atomicAdd(&stat[4], 1);
 }
@@ -629,6 +720,52 @@ __global__ void k_permute_out(int n, const int32_t* __restrict__ invp, const dou
   }
 }
 
+// ---- 64 x 64 triangular solves by ONE wave, operands in registers -------------------------------
+// The diagonal block is staged in LDS as blk[k][i] (= L11(i,k), leading dimension SB); lane i then
+// owns row i (forward) or column i (backward) in registers and the 64 dependent steps are a
+// v_readlane/shuffle + one FMA each: no memory access and no barrier inside the recurrence.
+constexpr int SB = 65;
+
+template <bool UNIT>
+__device__ __forceinline__ double wave_trsv_fwd(const double* blk, int nb, int lane, double yv) {
+  double row[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) row[k] = blk[k * SB + lane];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    if (k < nb) {
+      if (!UNIT && lane == k) yv /= row[k];
+      const double yk = __shfl(yv, k);
+      if (lane > k) yv -= row[k] * yk;
+    }
+  }
+  return yv;
+}
+
+template <bool UNIT>
+__device__ __forceinline__ double wave_trsv_bwd(const double* blk, int nb, int lane, double yv) {
+  double col[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) col[k] = blk[lane * SB + k];   // L11(k, lane), k >= lane meaningful
+#pragma unroll
+  for (int k = 63; k >= 0; --k) {
+    if (k < nb) {
+      if (!UNIT && lane == k) yv /= col[k];
+      const double yk = __shfl(yv, k);
+      if (lane < k) yv -= col[k] * yk;
+    }
+  }
+  return yv;
+}
+
+__device__ __forceinline__ void stage_block(double* blk, const double* __restrict__ Lb, int ld, int b,
+                                            int nb, int tid) {
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e & 63, k = e >> 6;
+    blk[k * SB + i] = (i < nb && k < nb && i >= k) ? Lb[int64_t(b + k) * ld + b + i] : 0.0;
+  }
+}
+
 // forward substitution on one front: gather children's contribution vectors, solve L11 y = rhs,
 // leave my contribution vector cvec = (children pass-through) - L21 y.
 // xp is indexed by analyse-time pivot position; gperm[sptr+i] is the position whose variable became
@@ -641,10 +778,11 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
             double* __restrict__ xp, double* __restrict__ cvec) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const NodeDesc nd = nodes[lvl[blockIdx.x]];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nd.n, cm = nd.m - nd.n;
-  double* yo = sh;       // n, analyse order
-  double* y = sh + n;    // n, pivot order
+  double* blk = sh;                 // 64 x SB
+  double* yo = sh + 64 * SB;        // n, analyse order
+  double* y = yo + n;               // n, pivot order
   const double* Lb = L + nd.loff;
   double* mine = cvec + nd.moff;
   for (int i = tid; i < n; i += 256) yo[i] = xp[nd.sptr + i];
@@ -663,24 +801,44 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     __syncthreads();
   }
   for (int i = tid; i < n; i += 256) y[i] = POSDEF ? yo[i] : yo[gperm[nd.sptr + i] - nd.sptr];
-  __syncthreads();
-  // column-oriented forward substitution
-  for (int k = 0; k < n; ++k) {
-    const double* col = Lb + int64_t(k) * nd.ld;
-    double yk = y[k];
-    if (POSDEF) yk /= col[k];
+  // blocked forward substitution
+  for (int b = 0; b < n; b += 64) {
+    const int nb = min(64, n - b);
     __syncthreads();
-    if (tid == 0) y[k] = yk;
-    for (int i = k + 1 + tid; i < n; i += 256) y[i] -= col[i] * yk;
+    stage_block(blk, Lb, nd.ld, b, nb, tid);
     __syncthreads();
+    if (wave == 0) {
+      const double v = wave_trsv_fwd<!POSDEF>(blk, nb, lane, (lane < nb) ? y[b + lane] : 0.0);
+      if (lane < nb) y[b + lane] = v;
+    }
+    __syncthreads();
+    // y[b+64 ..) -= L[b+64.., b..b+nb) * y[b..b+nb)
+    for (int i = b + 64 + tid; i < n; i += 256) {
+      double s = 0.0;
+      const double* row = Lb + int64_t(b) * nd.ld + i;
+#pragma unroll 8
+      for (int k = 0; k < nb; ++k) s += row[int64_t(k) * nd.ld] * y[b + k];
+      y[i] -= s;
+    }
   }
+  __syncthreads();
   for (int i = tid; i < n; i += 256) xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]] = y[i];
-  // cvec -= L21 * y : one thread per row, columns streamed (coalesced across threads)
-  for (int i = tid; i < cm; i += 256) {
-    double s = 0.0;
-    const double* row = Lb + n + i;
-    for (int k = 0; k < n; ++k) s += row[int64_t(k) * nd.ld] * y[k];
-    mine[i] -= s;
+  // cvec -= L21 * y : four threads per row split the columns (coalesced across rows)
+  {
+    const int q = tid >> 6;   // column quarter handled by this wave
+    for (int i0 = 0; i0 < cm; i0 += 64) {
+      const int i = i0 + lane;
+      double s = 0.0;
+      if (i < cm) {
+        const double* row = Lb + n + i;
+#pragma unroll 8
+        for (int k = q; k < n; k += 4) s += row[int64_t(k) * nd.ld] * y[k];
+      }
+      blk[q * 64 + lane] = s;
+      __syncthreads();
+      if (q == 0 && i < cm) mine[i] -= (blk[lane] + blk[64 + lane]) + (blk[128 + lane] + blk[192 + lane]);
+      __syncthreads();
+    }
   }
 }
 
@@ -714,8 +872,9 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
   const NodeDesc nd = nodes[lvl[blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nd.n, cm = nd.m - nd.n;
-  double* y = sh;       // n
-  double* z = sh + n;   // cm
+  double* blk = sh;              // 64 x SB
+  double* y = sh + 64 * SB;      // n
+  double* z = y + n;             // cm
   const double* Lb = L + nd.loff;
   const int32_t* rl = rlist + nd.roff + n;
   for (int i = tid; i < n; i += 256) y[i] = xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]];
@@ -725,25 +884,28 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
   for (int k = wave; k < n; k += 4) {
     const double* col = Lb + int64_t(k) * nd.ld + n;
     double s = 0.0;
+#pragma unroll 4
     for (int i = lane; i < cm; i += 64) s += col[i] * z[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if (lane == 0) y[k] -= s;
   }
-  __syncthreads();
-  // L11^T y = rhs, dot-product form, columns of L11 are rows of L11^T (contiguous)
-  if (wave == 0) {
-    for (int k = n - 1; k >= 0; --k) {
+  // blocked back substitution, last block first
+  for (int b = ((n - 1) / 64) * 64; b >= 0; b -= 64) {
+    const int nb = min(64, n - b);
+    __syncthreads();
+    // y[b..b+nb) -= L[b+64.., b..b+nb)^T y[b+64..)
+    for (int k = b + wave; k < b + nb; k += 4) {
       const double* col = Lb + int64_t(k) * nd.ld;
       double s = 0.0;
-      for (int i = k + 1 + lane; i < n; i += 64) s += col[i] * y[i];
+      for (int i = b + 64 + lane; i < n; i += 64) s += col[i] * y[i];
       for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-      if (lane == 0) {
-        double v = y[k] - s;
-        if (POSDEF) v /= col[k];
-        y[k] = v;
-      }
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
+      if (lane == 0) y[k] -= s;
+    }
+    stage_block(blk, Lb, nd.ld, b, nb, tid);
+    __syncthreads();
+    if (wave == 0) {
+      const double v = wave_trsv_bwd<!POSDEF>(blk, nb, lane, (lane < nb) ? y[b + lane] : 0.0);
+      if (lane < nb) y[b + lane] = v;
     }
   }
   __syncthreads();
@@ -766,17 +928,37 @@ static hipError_t upload(T*& dptr, const std::vector<T>& h, hipStream_t st) {
   return hipMemcpyAsync(dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
 }
 
+#ifdef GSLS_STAMPS
+extern "C" void gsls_debug_stamps(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
+
 void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
-                  F.xhost, F.stat, F.gperm};
+                  F.xhost, F.stat, F.gperm, F.asmtasks};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
 }
 
+static hipError_t allow_big_lds() {
+  const int big = 160 * 1024 - 512;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  return hipSuccess;
+}
+
 hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st) {
   dev_free(F);
+  HIPCHK(allow_big_lds());
   const int nn = S.nnodes;
   std::vector<NodeDesc> nd(nn);
   for (int s = 0; s < nn; ++s) {
@@ -813,6 +995,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<PanelTask> pt;
   std::vector<TileTask> tt;
   std::vector<int32_t> asmn;
+  std::vector<AsmTask> at;
   F.plan.assign(S.nlevels, LevelPlan());
   for (int l = 0; l < S.nlevels; ++l) {
     LevelPlan& lp = F.plan[l];
@@ -850,10 +1033,22 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         for (int ti = tj; ti < nt; ++ti) tt.push_back(TileTask{s, ti, tj, 0});
     }
     lp.tile_cnt = int(tt.size()) - lp.tile_begin;
+    // extend-add: child ranks 0..ASM_RANKS-1 as tiled launches, the rest one workgroup per parent
+    for (int rk = 0; rk < ASM_RANKS; ++rk) {
+      lp.asmt_begin[rk] = int(at.size());
+      for (int i = lp.node_begin; i < lp.node_end; ++i) {
+        const int s = S.lvlnodes[i];
+        if (S.cptr[s] + rk >= S.cptr[s + 1]) continue;
+        const int c = S.clist[S.cptr[s] + rk];
+        const int cm = S.nrow(c) - S.ncol(c);
+        for (int c0 = 0; c0 < cm; c0 += ACOLS) at.push_back(AsmTask{c, c0});
+      }
+      lp.asmt_cnt[rk] = int(at.size()) - lp.asmt_begin[rk];
+    }
     lp.asm_begin = int(asmn.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
       const int s = S.lvlnodes[i];
-      if (S.cptr[s + 1] > S.cptr[s]) asmn.push_back(s);
+      if (S.cptr[s + 1] - S.cptr[s] > ASM_RANKS) asmn.push_back(s);
     }
     lp.asm_cnt = int(asmn.size()) - lp.asm_begin;
   }
@@ -864,6 +1059,11 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(upload(F.clist, S.clist, st));
   HIPCHK(upload(F.lvlnodes, S.lvlnodes, st));
   HIPCHK(upload(F.asmnodes, asmn, st));
+  {
+    AsmTask* d = nullptr;
+    HIPCHK(upload(d, at, st));
+    F.asmtasks = d;
+  }
   HIPCHK(upload(F.asrc, asrc, st));
   HIPCHK(upload(F.adst, adst, st));
   HIPCHK(upload(F.arow, arow, st));
@@ -889,13 +1089,17 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
 template <bool POSDEF>
 static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small, double u,
                                 hipStream_t st) {
-  const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * PR * NB);
-  const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RB + NB * NB));
+  const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
+  const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = F.plan[l];
+    for (int rk = 0; rk < ASM_RANKS; ++rk)
+      if (lp.asmt_cnt[rk] > 0)
+        hipLaunchKernelGGL(k_assemble_tile, dim3(lp.asmt_cnt[rk]), dim3(256), 0, st, F.nodes,
+                           static_cast<const AsmTask*>(F.asmtasks) + lp.asmt_begin[rk], F.cmap, F.L, F.C);
     if (lp.asm_cnt > 0)
       hipLaunchKernelGGL(k_assemble, dim3(lp.asm_cnt), dim3(256), 0, st, F.nodes,
-                         F.asmnodes + lp.asm_begin, F.clist, F.cmap, F.L, F.C);
+                         F.asmnodes + lp.asm_begin, F.clist, F.cmap, F.L, F.C, ASM_RANKS);
     const int nsteps = int(lp.panel_cnt.size() / 2);
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
@@ -949,8 +1153,8 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
       int maxn = 0;
       for (int i = lp.node_begin; i < lp.node_end; ++i) maxn = std::max(maxn, S.ncol(S.lvlnodes[i]));
       hipLaunchKernelGGL(k_solve_fwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
-                         sizeof(double) * 2 * std::max(maxn, 1), st, F.nodes, F.lvlnodes + lp.node_begin,
-                         F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+                         sizeof(double) * (64 * 65 + 2 * std::max(maxn, 1)), st, F.nodes,
+                         F.lvlnodes + lp.node_begin, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
     }
   if (ev) HIPCHK(hipEventRecord(ev[1], st));
   if (do_diag)
@@ -962,8 +1166,8 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
       int maxm = 0;
       for (int i = lp.node_begin; i < lp.node_end; ++i) maxm = std::max(maxm, S.nrow(S.lvlnodes[i]));
       hipLaunchKernelGGL(k_solve_bwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
-                         sizeof(double) * std::max(maxm, 1), st, F.nodes, F.lvlnodes + lp.node_begin,
-                         F.rlist, F.gperm, F.L, xp);
+                         sizeof(double) * (64 * 65 + std::max(maxm, 1)), st, F.nodes,
+                         F.lvlnodes + lp.node_begin, F.rlist, F.gperm, F.L, xp);
     }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));
   return hipGetLastError();

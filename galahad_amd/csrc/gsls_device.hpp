@@ -12,6 +12,7 @@ namespace gsls {
 constexpr int NB = 64;   // block-column width of the panel factorization
 constexpr int RB = 64;   // row-chunk height handled by one workgroup
 constexpr int TS = 64;   // contribution-block tile edge
+constexpr int ASM_RANKS = 4;  // children of a parent assembled by tiled launches (one per rank)
 
 // One front.  L block: m x n column-major, leading dimension ld, at L + loff.
 // Contribution block: (m-n) x (m-n) column-major (lower triangle meaningful) at C + coff.
@@ -37,7 +38,8 @@ struct LevelPlan {
   int node_begin, node_end;                 // range in lvlnodes
   std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
   int tile_begin, tile_cnt;                 // range in the TileTask array
-  int asm_begin, asm_cnt;                   // parents with children: range in asm node list
+  int asm_begin, asm_cnt;                   // parents with > ASM_RANKS children: range in asm node list
+  int asmt_begin[ASM_RANKS], asmt_cnt[ASM_RANKS];   // tiled extend-add tasks per child rank
 };
 
 struct DeviceFactor {
@@ -48,6 +50,7 @@ struct DeviceFactor {
   int32_t* clist = nullptr;
   int32_t* lvlnodes = nullptr;
   int32_t* asmnodes = nullptr;
+  void* asmtasks = nullptr;
   int64_t* asrc = nullptr;     // A -> L scatter: source index in val
   int64_t* adst = nullptr;     //                 destination element in L
   int32_t* arow = nullptr;     // pivot positions (row, col) of each scattered entry, for scaling

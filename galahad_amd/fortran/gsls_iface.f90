@@ -1,0 +1,245 @@
+! GALAHAD_GSLS_double -- ISO_C_BINDING interface from GALAHAD's Fortran host code to the MI355X
+! sparse symmetric backend (C ABI: include/gsls.h, library: galahad_amd/libgsls.so).
+!
+! The public routines deliberately have the shape of the SPRAL-SSIDS calls that SLS makes today, so
+! that a `CASE ( 'gsls' )` arm in src/sls/sls.f90 is a copy of the `CASE ( 'ssids' )` arm with the
+! names changed (INTEGRATION.md shows the arms):
+!
+!   GSLS_analyse( n, ptr, row, keep, options, inform, order )      <-> ssids_analyse  ssids.f90:148
+!   GSLS_factor( posdef, val, keep, options, inform [, scale] )    <-> ssids_factor   ssids.f90:770
+!   GSLS_solve( x, keep, options, inform [, job] )                 <-> ssids_solve    ssids.f90:1114
+!   GSLS_solve_mult( nrhs, x, ldx, keep, options, inform [, job] ) <-> ssids_solve    ssids.f90:1139
+!   GSLS_enquire_posdef / GSLS_enquire_indef / GSLS_alter          <-> ssids.f90:1255-1384
+!   GSLS_free( keep )                                              <-> ssids_free     ssids.f90:1388
+!
+! gsls_keep plays the role of the (akeep, fkeep) pair: it owns the C handle (symbolic data, factors,
+! device memory).  gsls_options / gsls_inform are bind(C) mirrors of struct gsls_options /
+! struct gsls_inform and carry the fields of ssids_options / ssids_inform that SLS reads or sets
+! (src/sls/sls.f90:1385-1439, 1737-1786).
+module GALAHAD_GSLS_double
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+  public :: gsls_keep, gsls_options, gsls_inform
+  public :: GSLS_initialize, GSLS_analyse, GSLS_factor, GSLS_solve, GSLS_solve_mult
+  public :: GSLS_enquire_posdef, GSLS_enquire_indef, GSLS_alter, GSLS_free
+
+  integer, parameter :: wp = c_double
+  integer, parameter :: long = c_int64_t
+
+  type, bind(C) :: gsls_options
+    integer(c_int32_t) :: print_level = -1
+    integer(c_int32_t) :: ordering = 1      ! 0 user order, 1 built-in nested dissection, 3 natural
+    integer(c_int32_t) :: nemin = 32
+    integer(c_int32_t) :: scaling = 0
+    integer(c_int32_t) :: action = 1
+    integer(c_int32_t) :: device = -1
+    integer(c_int32_t) :: use_graph = 1
+    integer(c_int32_t) :: reserved0 = 0
+    real(c_double) :: u = 0.01_wp
+    real(c_double) :: small = 1.0e-20_wp
+    real(c_double) :: multiplier = 1.1_wp
+    real(c_double) :: reserved1 = 0.0_wp
+  end type gsls_options
+
+  type, bind(C) :: gsls_inform
+    integer(c_int32_t) :: flag = 0
+    integer(c_int32_t) :: matrix_dup = 0
+    integer(c_int32_t) :: matrix_missing_diag = 0
+    integer(c_int32_t) :: matrix_outrange = 0
+    integer(c_int32_t) :: matrix_rank = 0
+    integer(c_int32_t) :: maxdepth = 0
+    integer(c_int32_t) :: maxfront = 0
+    integer(c_int32_t) :: num_delay = 0
+    integer(c_int64_t) :: num_factor = 0
+    integer(c_int64_t) :: num_flops = 0
+    integer(c_int32_t) :: num_neg = 0
+    integer(c_int32_t) :: num_sup = 0
+    integer(c_int32_t) :: num_two = 0
+    integer(c_int32_t) :: stat = 0
+    integer(c_int32_t) :: hip_error = 0
+    integer(c_int32_t) :: not_first_pass = 0
+    integer(c_int32_t) :: nlevels = 0
+    integer(c_int32_t) :: reserved0 = 0
+    integer(c_int64_t) :: factor_bytes = 0
+    integer(c_int64_t) :: solve_bytes = 0
+    real(c_double) :: time_analyse = 0.0_wp
+    real(c_double) :: time_factor = 0.0_wp
+    real(c_double) :: time_solve = 0.0_wp
+    real(c_double) :: reserved1 = 0.0_wp
+  end type gsls_inform
+
+  type :: gsls_keep
+    type(c_ptr) :: handle = c_null_ptr
+    integer :: n = 0
+  end type gsls_keep
+
+  interface
+    subroutine c_gsls_default_options(options) bind(C, name='gsls_default_options')
+      import :: gsls_options
+      type(gsls_options), intent(out) :: options
+    end subroutine
+    integer(c_int) function c_gsls_create(handle) bind(C, name='gsls_create')
+      import :: c_ptr, c_int
+      type(c_ptr), intent(out) :: handle
+    end function
+    integer(c_int) function c_gsls_destroy(handle) bind(C, name='gsls_destroy')
+      import :: c_ptr, c_int
+      type(c_ptr), intent(inout) :: handle
+    end function
+    integer(c_int) function c_gsls_analyse(handle, n, ptr, row, order, options, inform) &
+        bind(C, name='gsls_analyse')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t, gsls_options, gsls_inform
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: n
+      integer(c_int64_t), intent(in) :: ptr(*)
+      integer(c_int32_t), intent(in) :: row(*)
+      integer(c_int32_t), intent(inout) :: order(*)
+      type(gsls_options), intent(in) :: options
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_factor(handle, posdef, val, scale, options, inform) &
+        bind(C, name='gsls_factor')
+      import :: c_ptr, c_int, c_int32_t, c_double, gsls_options, gsls_inform
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: posdef
+      real(c_double), intent(in) :: val(*)
+      type(c_ptr), value :: scale
+      type(gsls_options), intent(in) :: options
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_solve(handle, job, nrhs, x, ldx, options, inform) &
+        bind(C, name='gsls_solve')
+      import :: c_ptr, c_int, c_int32_t, c_double, gsls_options, gsls_inform
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: job, nrhs, ldx
+      real(c_double), intent(inout) :: x(*)
+      type(gsls_options), intent(in) :: options
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_enquire_posdef(handle, d, inform) bind(C, name='gsls_enquire_posdef')
+      import :: c_ptr, c_int, c_double, gsls_inform
+      type(c_ptr), value :: handle
+      real(c_double), intent(out) :: d(*)
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_enquire_indef(handle, piv_order, d, inform) &
+        bind(C, name='gsls_enquire_indef')
+      import :: c_ptr, c_int, gsls_inform
+      type(c_ptr), value :: handle
+      type(c_ptr), value :: piv_order, d
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_alter(handle, d, inform) bind(C, name='gsls_alter')
+      import :: c_ptr, c_int, c_double, gsls_inform
+      type(c_ptr), value :: handle
+      real(c_double), intent(in) :: d(*)
+      type(gsls_inform), intent(out) :: inform
+    end function
+  end interface
+
+contains
+
+  subroutine GSLS_initialize(keep, options)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(out) :: options
+    integer(c_int) :: rc
+    call c_gsls_default_options(options)
+    if (.not. c_associated(keep%handle)) rc = c_gsls_create(keep%handle)
+  end subroutine GSLS_initialize
+
+  ! order(i) = position of variable i in the pivot sequence; used on entry when options%ordering = 0,
+  ! always set on exit (ssids.f90:381)
+  subroutine GSLS_analyse(n, ptr, row, keep, options, inform, order)
+    integer, intent(in) :: n
+    integer(long), intent(in) :: ptr(:)
+    integer, intent(in) :: row(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    type(gsls_inform), intent(out) :: inform
+    integer, intent(inout) :: order(:)
+    integer(c_int) :: rc
+    if (.not. c_associated(keep%handle)) rc = c_gsls_create(keep%handle)
+    keep%n = n
+    rc = c_gsls_analyse(keep%handle, int(n, c_int32_t), ptr, row, order, options, inform)
+  end subroutine GSLS_analyse
+
+  subroutine GSLS_factor(posdef, val, keep, options, inform, scale)
+    logical, intent(in) :: posdef
+    real(wp), intent(in) :: val(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    type(gsls_inform), intent(out) :: inform
+    real(wp), optional, target, intent(in) :: scale(:)
+    integer(c_int) :: rc
+    type(c_ptr) :: sp
+    sp = c_null_ptr
+    if (present(scale)) sp = c_loc(scale)
+    rc = c_gsls_factor(keep%handle, merge(1_c_int32_t, 0_c_int32_t, posdef), val, sp, options, inform)
+  end subroutine GSLS_factor
+
+  subroutine GSLS_solve(x, keep, options, inform, job)
+    real(wp), intent(inout) :: x(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    type(gsls_inform), intent(out) :: inform
+    integer, optional, intent(in) :: job
+    integer(c_int) :: rc
+    integer(c_int32_t) :: j
+    j = 0
+    if (present(job)) j = int(job, c_int32_t)
+    rc = c_gsls_solve(keep%handle, j, 1_c_int32_t, x, int(max(keep%n, 1), c_int32_t), options, inform)
+  end subroutine GSLS_solve
+
+  subroutine GSLS_solve_mult(nrhs, x, ldx, keep, options, inform, job)
+    integer, intent(in) :: nrhs, ldx
+    real(wp), intent(inout) :: x(ldx, nrhs)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    type(gsls_inform), intent(out) :: inform
+    integer, optional, intent(in) :: job
+    integer(c_int) :: rc
+    integer(c_int32_t) :: j
+    j = 0
+    if (present(job)) j = int(job, c_int32_t)
+    rc = c_gsls_solve(keep%handle, j, int(nrhs, c_int32_t), x, int(ldx, c_int32_t), options, inform)
+  end subroutine GSLS_solve_mult
+
+  subroutine GSLS_enquire_posdef(keep, inform, d)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_inform), intent(out) :: inform
+    real(wp), intent(out) :: d(:)
+    integer(c_int) :: rc
+    rc = c_gsls_enquire_posdef(keep%handle, d, inform)
+  end subroutine GSLS_enquire_posdef
+
+  subroutine GSLS_enquire_indef(keep, inform, piv_order, d)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_inform), intent(out) :: inform
+    integer, optional, target, intent(out) :: piv_order(:)
+    real(wp), optional, target, intent(out) :: d(:, :)
+    integer(c_int) :: rc
+    type(c_ptr) :: pp, dp
+    pp = c_null_ptr ; dp = c_null_ptr
+    if (present(piv_order)) pp = c_loc(piv_order)
+    if (present(d)) dp = c_loc(d)
+    rc = c_gsls_enquire_indef(keep%handle, pp, dp, inform)
+  end subroutine GSLS_enquire_indef
+
+  subroutine GSLS_alter(d, keep, inform)
+    real(wp), intent(in) :: d(:, :)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_inform), intent(out) :: inform
+    integer(c_int) :: rc
+    rc = c_gsls_alter(keep%handle, d, inform)
+  end subroutine GSLS_alter
+
+  subroutine GSLS_free(keep, status)
+    type(gsls_keep), intent(inout) :: keep
+    integer, intent(out) :: status
+    status = 0
+    if (c_associated(keep%handle)) status = int(c_gsls_destroy(keep%handle))
+    keep%handle = c_null_ptr
+  end subroutine GSLS_free
+
+end module GALAHAD_GSLS_double
