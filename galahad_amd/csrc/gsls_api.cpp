@@ -6,6 +6,7 @@
 // There is deliberately no CPU numeric path: without a HIP device factor/solve fail with -51.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -28,6 +29,9 @@ struct Handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   gsls_inform last;  // statistics of analyse (+factor), returned again by later phases
+  std::vector<int64_t> ptr;   // the pattern given to analyse: needed again when failed pivots
+  std::vector<int32_t> row;   // force a repair of the elimination order (see repair_order)
+  int nemin = 32;
   double kt_fwd = 0, kt_diag = 0, kt_bwd = 0;
 };
 
@@ -88,6 +92,42 @@ void fill_from_symbolic(const Symbolic& S, gsls_inform* inf) {
   inf->num_flops = S.num_flops;
   inf->num_sup = S.nnodes;
   inf->nlevels = S.nlevels;
+}
+
+// Delayed pivots, MI355X style.  The reference passes a pivot that fails the threshold test up to the
+// parent front at run time (ssids/cpu/kernels/assemble.hxx:244-264): front sizes change during the
+// factorization and its GPU path re-plans every level on the host.  Here the schedule is static, so a
+// failed pivot is turned into a change of the ELIMINATION ORDER instead: the variable is moved to the
+// end of its own supernode (if later 64-column blocks remain there) or to just after the last column
+// of the parent supernode, the symbolic analysis is redone for that order and the factorization
+// repeated.  The numerical effect is the same -- the variable is eliminated in the parent front,
+// after more of its row is fully summed -- and the repaired order is kept in the handle, so later
+// factorizations of the same structure (the interior-point loop of CQP/SBLS) start from it.
+// Returns false when nothing can be moved (failure in the last block of a root).
+bool repair_order(const Symbolic& S, const std::vector<int32_t>& failed_pos, std::vector<int32_t>& order) {
+  const int n = S.n, nn = S.nnodes;
+  std::vector<double> key(n);
+  for (int p = 0; p < n; ++p) key[p] = double(p);
+  bool moved = false;
+  for (int32_t p : failed_pos) {
+    if (p < 0 || p >= n) continue;
+    const int s = int(std::upper_bound(S.sptr.begin(), S.sptr.begin() + nn + 1, p) - S.sptr.begin()) - 1;
+    if (s < 0 || s >= nn) continue;
+    const int blk = (p - S.sptr[s]) / NB, nblk = (S.ncol(s) + NB - 1) / NB;
+    int target;
+    if (blk < nblk - 1) target = S.sptr[s + 1] - 1;
+    else if (S.sparent[s] < nn) target = S.sptr[S.sparent[s] + 1] - 1;
+    else continue;
+    key[p] = double(target) + 0.5;
+    moved = true;
+  }
+  if (!moved) return false;
+  std::vector<int> idx(n);
+  for (int p = 0; p < n; ++p) idx[p] = p;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+  order.assign(n, 0);
+  for (int newpos = 0; newpos < n; ++newpos) order[S.invp[idx[newpos]]] = newpos + 1;
+  return true;
 }
 
 }  // namespace
@@ -171,6 +211,9 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
       for (int64_t k = 0; k < ptr[n] - 1; ++k)
         if (row[k] < 1 || row[k] > n) return inform->flag = GSLS_ERROR_A_ALL_OOR;
       flag = symbolic_analyse(n, ptr, row, order, options->ordering, options->nemin, h->S);
+      h->ptr.assign(ptr, ptr + n + 1);
+      h->row.assign(row, row + (ptr[n] - 1));
+      h->nemin = options->nemin;
     }
   } catch (const std::bad_alloc&) {
     inform->stat = 1;
@@ -222,46 +265,78 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   DeviceFactor& F = h->F;
   const double* d_val = val;
   const double* d_scale = scale;
-  if (!on_device) {
-    // ptr/row are not kept (check=.false. semantics, ssids.f90:869-877): the value count is the
-    // number of scattered entries
-    const int64_t nz = F.nscatter;
-    if (F.val_cap < nz) {
-      if (F.val) (void)hipFree(F.val);
-      F.val = nullptr;
-      e = hipMalloc(reinterpret_cast<void**>(&F.val), std::max<int64_t>(nz, 1) * sizeof(double));
-      if (e != hipSuccess) return fail_hip(h, inform, e);
-      F.val_cap = nz;
+  auto stage_inputs = [&]() -> hipError_t {
+    if (!on_device) {
+      // ptr/row are kept from analyse; the value count is the number of scattered entries
+      const int64_t nz = F.nscatter;
+      if (F.val_cap < nz) {
+        if (F.val) (void)hipFree(F.val);
+        F.val = nullptr;
+        hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&F.val), std::max<int64_t>(nz, 1) * sizeof(double));
+        if (e2 != hipSuccess) return e2;
+        F.val_cap = nz;
+      }
+      hipError_t e2 = hipMemcpyAsync(F.val, val, nz * sizeof(double), hipMemcpyHostToDevice, h->stream);
+      if (e2 != hipSuccess) return e2;
+      d_val = F.val;
     }
-    e = hipMemcpyAsync(F.val, val, nz * sizeof(double), hipMemcpyHostToDevice, h->stream);
-    if (e != hipSuccess) return fail_hip(h, inform, e);
-    d_val = F.val;
     if (scale) {
       if (!F.scale) {
-        e = hipMalloc(reinterpret_cast<void**>(&F.scale), S.n * sizeof(double));
-        if (e != hipSuccess) return fail_hip(h, inform, e);
+        hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&F.scale), h->S.n * sizeof(double));
+        if (e2 != hipSuccess) return e2;
       }
-      e = hipMemcpyAsync(F.scale, scale, S.n * sizeof(double), hipMemcpyHostToDevice, h->stream);
-      if (e != hipSuccess) return fail_hip(h, inform, e);
+      hipError_t e2 = hipMemcpyAsync(F.scale, scale, h->S.n * sizeof(double),
+                                     on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream);
+      if (e2 != hipSuccess) return e2;
       d_scale = F.scale;
     }
-  } else if (scale) {
-    if (!F.scale) {
-      e = hipMalloc(reinterpret_cast<void**>(&F.scale), S.n * sizeof(double));
+    return hipSuccess;
+  };
+  e = stage_inputs();
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  h->have_scale = (scale != nullptr);
+  int32_t st[16];
+  int total_moved = 0;
+  const int max_pass = 200;
+  for (int pass = 0;; ++pass) {
+    e = dev_factor(h->S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    e = hipMemcpyAsync(st, F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    if (posdef || st[4] == 0) break;
+    // ---- some pivots failed: repair the elimination order and go again ---------------------------
+    const int nf = std::min<int>(st[5], FAILCAP);
+    std::vector<int32_t> failed(nf), order;
+    if (nf > 0) {
+      e = hipMemcpy(failed.data(), F.faillist, nf * sizeof(int32_t), hipMemcpyDeviceToHost);
       if (e != hipSuccess) return fail_hip(h, inform, e);
     }
-    e = hipMemcpyAsync(F.scale, scale, S.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+    std::sort(failed.begin(), failed.end());
+    failed.erase(std::unique(failed.begin(), failed.end()), failed.end());
+    if (pass >= max_pass || !repair_order(h->S, failed, order)) {
+      inform->num_delay = total_moved;
+      inform->flag = GSLS_ERROR_UNIMPLEMENTED;   // could not place the failed pivots
+      inform->time_factor = now() - t0;
+      return inform->flag;
+    }
+    total_moved += int(failed.size());
+    int flag2;
+    try {
+      flag2 = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER,
+                               h->nemin, h->S);
+    } catch (const std::bad_alloc&) {
+      return inform->flag = GSLS_ERROR_ALLOCATION;
+    }
+    if (flag2 < 0) return inform->flag = flag2;
+    fill_from_symbolic(h->S, inform);
+    inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+    e = dev_upload_symbolic(h->S, F, h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
-    d_scale = F.scale;
+    e = stage_inputs();
+    if (e != hipSuccess) return fail_hip(h, inform, e);
   }
-  h->have_scale = (scale != nullptr);
-  e = dev_factor(S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream);
-  if (e != hipSuccess) return fail_hip(h, inform, e);
-  int32_t st[16];
-  e = hipMemcpyAsync(st, F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
-  if (e != hipSuccess) return fail_hip(h, inform, e);
-  e = hipStreamSynchronize(h->stream);
-  if (e != hipSuccess) return fail_hip(h, inform, e);
 
   h->posdef = posdef != 0;
   inform->num_neg = 0;
@@ -279,14 +354,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   } else {
     inform->num_neg = st[2];
     inform->num_two = st[3];
-    inform->num_delay = st[4];
-    if (st[4] > 0) {
-      // a pivot failed the a-posteriori threshold test: the optimistic, statically scheduled pass is
-      // not valid for this matrix (the reference would delay the pivot to the parent front)
-      inform->flag = GSLS_ERROR_UNIMPLEMENTED;
-      inform->time_factor = now() - t0;
-      return inform->flag;
-    }
+    inform->num_delay = total_moved;
     if (st[1] > 0) {
       inform->matrix_rank -= st[1];
       if (!options->action) {

@@ -321,7 +321,7 @@ __device__ __forceinline__ void swap_sym(double* P, int32_t* lperm, int pr, int 
 __global__ void __launch_bounds__(256)
 k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
             double* __restrict__ L, double* __restrict__ D, int32_t* __restrict__ gperm,
-            int32_t* __restrict__ stat, double small, double u) {
+            int32_t* __restrict__ stat, int32_t* __restrict__ faillist, double small, double u) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);
@@ -373,7 +373,8 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   const int r = tid & (PR - 1), kofs = tid >> 7;
   const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
   int nfail = 0;      // uniform
-  bool big = false;   // per thread: an |l| above 1/u below the block
+  int fail_from = NB; // uniform: columns [fail_from, w) of the block could not be eliminated here
+  int bigcol = NB;    // per thread: first column with an |l| above 1/u below the block
   int p = 0;
   while (p < w) {
     // ---- largest remaining entry of the block (lower triangle, rows/cols p..w-1) ----
@@ -405,7 +406,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       bool nz = false;
       if (kofs == 0 && r >= w && r < pr)
         for (int c = p; c < w; ++c) nz |= !(fabs(P[c * LDP + r]) < small);
-      if (__syncthreads_or(nz)) nfail += w - p;
+      if (__syncthreads_or(nz)) { nfail += w - p; fail_from = p; }
       for (int c = p + kofs; c < w; c += 2)
         if (r > c && r < pr) P[c * LDP + r] = 0.0;
       if (tid >= p && tid < w) { dg[2 * tid] = 0.0; dg[2 * tid + 1] = 0.0; }
@@ -436,7 +437,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       }
     }
     __syncthreads();   // every thread has read the candidates
-    if (pivsiz == 0) { nfail += w - p; break; }
+    if (pivsiz == 0) { nfail += w - p; fail_from = p; break; }
     if (pivsiz == 1) {
       swap_sym(P, lperm, pr, p, trow, tid);
       __syncthreads();
@@ -449,7 +450,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       if (kofs == 0) {
         if (r > p && r < pr) {
           P[p * LDP + r] = l;
-          if (r >= w && fabs(l) > inv_u) big = true;
+          if (r >= w && fabs(l) > inv_u) bigcol = min(bigcol, p);
         }
         if (r == p) { P[p * LDP + p] = 1.0; dg[2 * p] = d11; dg[2 * p + 1] = 0.0; }
       }
@@ -473,7 +474,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         if (r > p + 1 && r < pr) {
           P[p * LDP + r] = l1;
           P[(p + 1) * LDP + r] = l2;
-          if (r >= w && (fabs(l1) > inv_u || fabs(l2) > inv_u)) big = true;
+          if (r >= w && (fabs(l1) > inv_u || fabs(l2) > inv_u)) bigcol = min(bigcol, p);
         }
         if (r == p) {
           P[p * LDP + p] = 1.0; P[p * LDP + p + 1] = 0.0; P[(p + 1) * LDP + p + 1] = 1.0;
@@ -485,7 +486,14 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     }
   }
   __syncthreads();
-  if (__syncthreads_or(big)) nfail = max(nfail, 1);
+  // first column that failed the a-posteriori test (min over the workgroup, via LDS)
+  __shared__ int32_t s_bigcol;
+  if (tid == 0) s_bigcol = NB;
+  __syncthreads();
+  if (bigcol < NB) atomicMin(&s_bigcol, bigcol);
+  __syncthreads();
+  bigcol = s_bigcol;
+  if (bigcol < NB) nfail = max(nfail, 1);
 
   // ---- store: factors, pivots, the permutation, inertia ----------------------------------------------
   for (int e = tid; e < pr * w; e += 256) {
@@ -526,7 +534,17 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     if (nzero) atomicAdd(&stat[1], nzero);
     if (nneg) atomicAdd(&stat[2], nneg);
     if (ntwo) atomicAdd(&stat[3], ntwo);
-    if (nfail) atomicAdd(&stat[4], nfail);
+    if (nfail) {
+      atomicAdd(&stat[4], nfail);
+      // report which variables (analyse-time pivot positions) must be eliminated later
+      const int b2 = (bigcol < NB) ? bigcol + ((bigcol + 1 < w && isinf(dg[2 * bigcol + 2])) ? 2 : 1) : bigcol;
+      for (int j = 0; j < w; ++j) {
+        const bool bad = (j >= fail_from) || (bigcol < NB && j >= bigcol && j < b2);
+        if (!bad) continue;
+        const int slot = atomicAdd(&stat[5], 1);
+        if (slot < FAILCAP) faillist[slot] = nd.sptr + kb + lperm[j];
+      }
+    }
   }
 }
 
@@ -540,7 +558,7 @@ template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         double* __restrict__ L, const double* __restrict__ D, const int32_t* __restrict__ gperm,
-        int32_t* __restrict__ stat, double u) {
+        int32_t* __restrict__ stat, int32_t* __restrict__ faillist, double u) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
   double* Pc = reinterpret_cast<double*>(smem_raw);                  // [w][RBP]
@@ -602,7 +620,7 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
   // column c in registers (static indices, run-time column loop); per column: its owners publish the
   // finished (L D) column, one barrier, the columns to the right take their update.
   const double inv_u = (!POSDEF && u > 0.0) ? 1.0 / u : INFINITY;
-  bool big = false;
+  int bigcol = NB;   // first column whose multiplier breaks |l| <= 1/u in this chunk
   {
     const int c = tid & 63, q = tid >> 6;
     double a[16];
@@ -642,20 +660,35 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         const double a1 = Pc[(j - 1) * RBP + r];
         const double l2 = dsc[2 * j - 1] * a1 + dsc[2 * j + 1] * aj;
         *out = l2;
-        if (fabs(l2) > inv_u) big = true;
+        if (fabs(l2) > inv_u) bigcol = min(bigcol, j - 1);
       } else if (j + 1 < w && isinf(dsc[2 * j + 2])) {
         const double a2 = Pc[(j + 1) * RBP + r];
         const double l1 = dsc[2 * j] * aj + dsc[2 * j + 1] * a2;
         *out = l1;
-        if (fabs(l1) > inv_u) big = true;
+        if (fabs(l1) > inv_u) bigcol = min(bigcol, j);
       } else {
         const double l = aj * dsc[2 * j];
         *out = l;
-        if (fabs(l) > inv_u) big = true;
+        if (fabs(l) > inv_u) bigcol = min(bigcol, j);
       }
     }
   }
-  if (!POSDEF && __syncthreads_or(big) && tid == 0) atomicAdd(&stat[4], 1);
+  if (!POSDEF) {
+    __shared__ int32_t s_bigcol;
+    if (tid == 0) s_bigcol = NB;
+    __syncthreads();
+    if (bigcol < NB) atomicMin(&s_bigcol, bigcol);
+    __syncthreads();
+    if (tid == 0 && s_bigcol < NB) {
+      const int j = s_bigcol;
+      const int cnt = (j + 1 < w && isinf(dsc[2 * j + 2])) ? 2 : 1;
+      atomicAdd(&stat[4], cnt);
+      for (int k = j; k < j + cnt; ++k) {
+        const int slot = atomicAdd(&stat[5], 1);
+        if (slot < FAILCAP) faillist[slot] = gperm[nd.sptr + kb + k];
+      }
+    }
+  }
 }
 
 // =================================================================================================
@@ -937,7 +970,7 @@ extern "C" void gsls_debug_stamps(unsigned long long* out) {
 void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
-                  F.xhost, F.stat, F.gperm, F.asmtasks};
+                  F.xhost, F.stat, F.gperm, F.asmtasks, F.faillist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -1081,6 +1114,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gperm), std::max(S.n, 1) * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), std::max<int64_t>(F.cvec_elems, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), 16 * sizeof(int32_t)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.faillist), FAILCAP * sizeof(int32_t)));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
   return hipSuccess;
 }
@@ -1108,11 +1142,11 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small
                              F.ptasks + lp.panel_begin[2 * s], F.L, F.stat);
         else
           hipLaunchKernelGGL(k_diag_ldlt, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, small, u);
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, F.faillist, small, u);
       }
       if (lp.panel_cnt[2 * s + 1] > 0)
         hipLaunchKernelGGL(k_panel<POSDEF>, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_panel, st,
-                           F.nodes, F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, u);
+                           F.nodes, F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u);
     }
     if (lp.tile_cnt > 0)
       hipLaunchKernelGGL(k_contrib<POSDEF>, dim3(lp.tile_cnt), dim3(256), 0, st, F.nodes,

@@ -12,6 +12,7 @@ namespace gsls {
 constexpr int NB = 64;   // block-column width of the panel factorization
 constexpr int RB = 64;   // row-chunk height handled by one workgroup
 constexpr int TS = 64;   // contribution-block tile edge
+constexpr int FAILCAP = 16384;  // capacity of the failed-pivot report of one factorization pass
 constexpr int ASM_RANKS = 4;  // children of a parent assembled by tiled launches (one per rank)
 
 // One front.  L block: m x n column-major, leading dimension ld, at L + loff.
@@ -70,6 +71,7 @@ struct DeviceFactor {
   double* xp = nullptr;        // permuted solution / rhs workspace (n * nrhs_cap)
   double* cvec = nullptr;      // per-node contribution vectors for the forward solve
   double* xhost = nullptr;     // staging for host x
+  int32_t* faillist = nullptr; // analyse-time positions of pivots that failed in the last pass
   int32_t* stat = nullptr;     // [0] first failing pivot position+1 (posdef) / flag, [1] zero pivots,
                                // [2] num_neg, [3] num_two, [4] delays
   int64_t L_elems = 0, C_elems = 0, cvec_elems = 0;
