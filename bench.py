@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--ordering", choices=["free", "natural"], default="free",
                     help="free: the backend's own ordering (perf run); natural: identity PERM (parity run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nemin", type=int, default=0, help="supernode amalgamation (0: backend default)")
     return ap.parse_args()
 
 
@@ -111,6 +112,8 @@ def main():
     s.opts.device = local_rank
     if a.ordering == "natural":
         c.ordering = 0
+    if a.nemin > 0:
+        c.node_amalgamation = a.nemin
     t0 = time.perf_counter()
     s.analyse(m, c, inf)
     t_analyse = time.perf_counter() - t0
@@ -176,7 +179,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SLS standalone: random banded SPD n=%d, semi-bandwidth=%d, fp64 "
                                    "(BASELINE.json configs[1]); one system per GPU" % (a.n, a.semibw),
-                       "ordering": a.ordering, "flops_numerator": F,
+                       "ordering": a.ordering, "node_amalgamation": c.node_amalgamation, "flops_numerator": F,
                        "flops_executed_per_step": flops_used, "entries_in_factors": nnzL,
                        "levels": inf.gsls_inform["nlevels"], "supernodes": inf.gsls_inform["num_sup"],
                        "analyse_s": t_analyse, "scaled_residual": res},

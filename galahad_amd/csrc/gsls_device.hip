@@ -28,8 +28,10 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #ifdef GSLS_STAMPS   // diagnostic build only: in-kernel phase stamps (s_memtime), never in the product
 __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPN(i) do { __syncthreads(); if (threadIdx.x == 0 && nd.m > 300 && nd.n > 100 && nd.m > nd.n) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMPN(i) do {} while (0)
 #endif
 
 #define HIPCHK(call)                    \
@@ -158,16 +160,34 @@ __device__ __forceinline__ void mfma_panel(const Stage<AROWS>& sg, int rbase, in
 // columns [k0, k0+KC) (valid < kmax) of the front at Lb.  With dinv != nullptr the B panel is
 // (L*D): D is held inverted, 1x1 as [d,0], 2x2 as [d11,d21,inf,d22] (ldlt_app.cxx:324-329), and
 // L*D is formed as in calc_ld.hxx:43-118.
+// Operand staging for the MFMA updates, split in two halves so that the loads of K-chunk k+1 are in
+// flight while chunk k is multiplied (register double buffering; the LDS image is single):
+//   stage_load : rows [arow0, arow0+AROWS) (valid < amax) and rows [brow0, brow0+64) (valid < bmax)
+//                of columns [k0, k0+KC) (valid < kmax) of the front at Lb -> registers.  With
+//                dinv != nullptr the B panel is (L*D): D is held inverted, 1x1 as [d,0], 2x2 as
+//                [d11,d21,inf,d22] (ldlt_app.cxx:324-329); L*D as in calc_ld.hxx:43-118.
+//   stage_store: registers -> LDS.
 template <int AROWS>
-__device__ __forceinline__ void stage_panels(Stage<AROWS>& sg, const double* __restrict__ Lb, int ld,
-                                             int arow0, int amax, int brow0, int bmax, int k0,
-                                             int kmax, const double* __restrict__ dinv, int tid) {
-  for (int e = tid; e < AROWS * KC; e += 256) {
+struct StageRegs {
+  double va[AROWS * KC / 256];
+  double vb[64 * KC / 256];
+};
+
+template <int AROWS>
+__device__ __forceinline__ void stage_load(StageRegs<AROWS>& rg, const double* __restrict__ Lb, int ld,
+                                           int arow0, int amax, int brow0, int bmax, int k0, int kmax,
+                                           const double* __restrict__ dinv, int tid) {
+  constexpr int NA = AROWS * KC / 256, NBL = 64 * KC / 256;
+#pragma unroll
+  for (int t = 0; t < NA; ++t) {
+    const int e = tid + 256 * t;
     const int r = e % AROWS, kk = e / AROWS;
     const int gr = arow0 + r, gk = k0 + kk;
-    sg.As[kk][r] = (gr < amax && gk < kmax) ? Lb[int64_t(gk) * ld + gr] : 0.0;
+    rg.va[t] = (gr < amax && gk < kmax) ? Lb[int64_t(gk) * ld + gr] : 0.0;
   }
-  for (int e = tid; e < 64 * KC; e += 256) {
+#pragma unroll
+  for (int t = 0; t < NBL; ++t) {
+    const int e = tid + 256 * t;
     const int r = e & 63, kk = e >> 6;
     const int gr = brow0 + r, gk = k0 + kk;
     const bool ok = (gr < bmax && gk < kmax);
@@ -186,7 +206,22 @@ __device__ __forceinline__ void stage_panels(Stage<AROWS>& sg, const double* __r
         v = (d0 != 0.0) ? v / d0 : 0.0;                  // zero pivots just give zeros
       }
     }
-    sg.Bs[kk][r] = v;
+    rg.vb[t] = v;
+  }
+}
+
+template <int AROWS>
+__device__ __forceinline__ void stage_store(Stage<AROWS>& sg, const StageRegs<AROWS>& rg, int tid) {
+  constexpr int NA = AROWS * KC / 256, NBL = 64 * KC / 256;
+#pragma unroll
+  for (int t = 0; t < NA; ++t) {
+    const int e = tid + 256 * t;
+    sg.As[e / AROWS][e % AROWS] = rg.va[t];
+  }
+#pragma unroll
+  for (int t = 0; t < NBL; ++t) {
+    const int e = tid + 256 * t;
+    sg.Bs[e >> 6][e & 63] = rg.vb[t];
   }
 }
 
@@ -222,16 +257,22 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < kb; k0 += KC) {
-    __syncthreads();
-    stage_panels<PR>(sg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0, kb, nullptr, tid);
-    __syncthreads();
-    mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
+  if (kb > 0) {
+    StageRegs<PR> rg;
+    stage_load<PR>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, 0, kb, nullptr, tid);
+    for (int k0 = 0; k0 < kb; k0 += KC) {
+      __syncthreads();
+      stage_store<PR>(sg, rg, tid);
+      __syncthreads();
+      if (k0 + KC < kb) stage_load<PR>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0 + KC, kb, nullptr, tid);
+      mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
+    }
   }
   __syncthreads();
   STAMP(1);
   {
     const int lr = lane & 15, lq = lane >> 4;
+    double g[2][4][4];   // all 32 loads in flight before the first LDS store
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -240,9 +281,17 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         for (int r = 0; r < 4; ++r) {
           const int row = 32 * wave + 16 * i + lq + 4 * r;
           const int col = 16 * j + lr;
-          double v = 0.0;
-          if (row < pr && col < w) v = Lb[int64_t(kb + col) * nd.ld + kb + row] - acc[i][j][r];
-          P[col * LDP + row] = v;
+          g[i][j][r] = (row < pr && col < w) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * wave + 16 * i + lq + 4 * r;
+          const int col = 16 * j + lr;
+          P[col * LDP + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : 0.0;
         }
   }
   __syncthreads();
@@ -260,7 +309,8 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   __syncthreads();
   STAMP(3);
   double* colbuf = P;            // 2 x PR doubles, double buffered (the panel now lives in registers)
-  bool failed = false;
+  double* dpiv = P + 2 * PR;     // the w pivots d_j; columns stay UNscaled (a = l * sqrt(d)) until the end,
+  bool failed = false;           // which keeps sqrt and the owner's scaling off the per-pivot critical path
   for (int j = 0; j < w; ++j) {
     double* cb = colbuf + (j & 1) * PR;
     if (c == j) {
@@ -273,18 +323,21 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + j);
       failed = true;
     }
+    if (tid == 0) dpiv[j] = d;
     if (c > j) {
-      const double f = cb[c] / d;            // a(c,j) / d
+      const double f = cb[c] / d;            // a(c,j) / d_j
 #pragma unroll
       for (int i = 0; i < 32; ++i) a[i] -= cb[32 * q + i] * f;
-    } else if (c == j) {
-      const double s = sqrt(d), is = 1.0 / s;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) a[i] = (32 * q + i == j) ? s : a[i] * is;
     }
   }
   __syncthreads();
-  STAMP(4);
+  {
+    const double dc = (c < w) ? dpiv[c] : 1.0;
+    const double s = sqrt(dc), is = 1.0 / s;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a[i] = (32 * q + i == c) ? s : a[i] * is;
+  }
+  __syncthreads();
   // ---- back through LDS so that the store to HBM is coalesced along rows -----------------------------
 #pragma unroll
   for (int i = 0; i < 32; ++i) P[c * LDP + 32 * q + i] = a[i];
@@ -345,15 +398,21 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < kb; k0 += KC) {
-    __syncthreads();
-    stage_panels<PR>(sg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0, kb, dinv, tid);
-    __syncthreads();
-    mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
+  if (kb > 0) {
+    StageRegs<PR> rg;
+    stage_load<PR>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, 0, kb, dinv, tid);
+    for (int k0 = 0; k0 < kb; k0 += KC) {
+      __syncthreads();
+      stage_store<PR>(sg, rg, tid);
+      __syncthreads();
+      if (k0 + KC < kb) stage_load<PR>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0 + KC, kb, dinv, tid);
+      mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
+    }
   }
   __syncthreads();
   {
     const int lr = lane & 15, lq = lane >> 4;
+    double g[2][4][4];   // all 32 loads in flight before the first LDS store
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -362,9 +421,17 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         for (int r = 0; r < 4; ++r) {
           const int row = 32 * wave + 16 * i + lq + 4 * r;
           const int col = 16 * j + lr;
-          double v = 0.0;
-          if (row < pr && col < w) v = Lb[int64_t(kb + col) * nd.ld + kb + row] - acc[i][j][r];
-          P[col * LDP + row] = v;
+          g[i][j][r] = (row < pr && col < w) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * wave + 16 * i + lq + 4 * r;
+          const int col = 16 * j + lr;
+          P[col * LDP + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : 0.0;
         }
   }
   if (tid < NB) lperm[tid] = tid;
@@ -582,16 +649,22 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
   const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
-  for (int k0 = 0; k0 < kb; k0 += KC) {
-    __syncthreads();
-    stage_panels<RB>(sg, Lb, nd.ld, r0, nd.m, kb, kb + w, k0, kb, dinv, tid);
-    __syncthreads();
-    mfma_panel<RB, 2, 2>(sg, wr, wc, lane, acc);
+  if (kb > 0) {
+    StageRegs<RB> rg;
+    stage_load<RB>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, 0, kb, dinv, tid);
+    for (int k0 = 0; k0 < kb; k0 += KC) {
+      __syncthreads();
+      stage_store<RB>(sg, rg, tid);
+      __syncthreads();
+      if (k0 + KC < kb) stage_load<RB>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, k0 + KC, kb, dinv, tid);
+      mfma_panel<RB, 2, 2>(sg, wr, wc, lane, acc);
+    }
   }
   if (tid < NB) lp[tid] = (POSDEF || tid >= w) ? tid : gperm[nd.sptr + kb + tid] - (nd.sptr + kb);
   __syncthreads();
   {
     const int lr = lane & 15, lq = lane >> 4;
+    double g[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -600,14 +673,31 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         for (int r = 0; r < 4; ++r) {
           const int row = wr + 16 * i + lq + 4 * r;
           const int col = wc + 16 * j + lr;
-          double v = 0.0;   // the block's pivoting permuted its columns: gather column lp[col] of A
-          if (row < rows && col < w) v = Lb[int64_t(kb + lp[col]) * nd.ld + r0 + row] - acc[i][j][r];
-          Pc[col * RBP + row] = v;
+          // the block's pivoting permuted its columns: gather column lp[col] of A
+          g[i][j][r] = (row < rows && col < w) ? Lb[int64_t(kb + lp[col]) * nd.ld + r0 + row] : 0.0;
         }
-  }
-  for (int e = tid; e < w * w; e += 256) {
-    const int row = e % w, col = e / w;
-    L11[col * NB + row] = (row >= col) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
+    double l11[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = tid + 256 * t;
+      const int row = e & 63, col = e >> 6;
+      l11[t] = (row < w && col < w && row >= col) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr + 16 * i + lq + 4 * r;
+          const int col = wc + 16 * j + lr;
+          Pc[col * RBP + row] = (row < rows && col < w) ? g[i][j][r] - acc[i][j][r] : 0.0;
+        }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = tid + 256 * t;
+      L11[(e >> 6) * NB + (e & 63)] = l11[t];
+    }
   }
   if (POSDEF) {
     if (tid < w) dsc[tid] = 1.0 / Lb[int64_t(kb + tid) * nd.ld + kb + tid];
@@ -713,11 +803,16 @@ k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
   const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
-  for (int k0 = 0; k0 < nd.n; k0 += KC) {
-    __syncthreads();
-    stage_panels<TS>(sg, Lb, nd.ld, ar0, nd.m, br0, nd.m, k0, nd.n, dinv, tid);
-    __syncthreads();
-    mfma_panel<TS, 2, 2>(sg, wr, wc, lane, acc);
+  {
+    StageRegs<TS> rg;
+    stage_load<TS>(rg, Lb, nd.ld, ar0, nd.m, br0, nd.m, 0, nd.n, dinv, tid);
+    for (int k0 = 0; k0 < nd.n; k0 += KC) {
+      __syncthreads();
+      stage_store<TS>(sg, rg, tid);
+      __syncthreads();
+      if (k0 + KC < nd.n) stage_load<TS>(rg, Lb, nd.ld, ar0, nd.m, br0, nd.m, k0 + KC, nd.n, dinv, tid);
+      mfma_panel<TS, 2, 2>(sg, wr, wc, lane, acc);
+    }
   }
   double* Cb = C + nd.coff;
   const int lr = lane & 15, lq = lane >> 4;
@@ -729,7 +824,18 @@ k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks
       for (int r = 0; r < 4; ++r) {
         const int row = t.ti * TS + wr + 16 * i + lq + 4 * r;
         const int col = t.tj * TS + wc + 16 * j + lr;
-        if (row < cm && col < cm && row >= col) Cb[int64_t(col) * cm + row] -= acc[i][j][r];
+        const bool ok = (row < cm && col < cm && row >= col);
+        acc[i][j][r] = (ok ? Cb[int64_t(col) * cm + row] : 0.0) - acc[i][j][r];
+      }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = t.ti * TS + wr + 16 * i + lq + 4 * r;
+        const int col = t.tj * TS + wc + 16 * j + lr;
+        if (row < cm && col < cm && row >= col) Cb[int64_t(col) * cm + row] = acc[i][j][r];
       }
 }
 
@@ -759,16 +865,23 @@ __global__ void k_permute_out(int n, const int32_t* __restrict__ invp, const dou
 // v_readlane/shuffle + one FMA each: no memory access and no barrier inside the recurrence.
 constexpr int SB = 65;
 
+__device__ __forceinline__ double readlane_f64(double v, int k) {   // k wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
 template <bool UNIT>
 __device__ __forceinline__ double wave_trsv_fwd(const double* blk, int nb, int lane, double yv) {
   double row[64];
 #pragma unroll
   for (int k = 0; k < 64; ++k) row[k] = blk[k * SB + lane];
+  const double rd = UNIT ? 1.0 : 1.0 / blk[lane * SB + lane];   // one division, off the recurrence
 #pragma unroll
   for (int k = 0; k < 64; ++k) {
     if (k < nb) {
-      if (!UNIT && lane == k) yv /= row[k];
-      const double yk = __shfl(yv, k);
+      if (!UNIT && lane == k) yv *= rd;
+      const double yk = readlane_f64(yv, k);
       if (lane > k) yv -= row[k] * yk;
     }
   }
@@ -780,11 +893,12 @@ __device__ __forceinline__ double wave_trsv_bwd(const double* blk, int nb, int l
   double col[64];
 #pragma unroll
   for (int k = 0; k < 64; ++k) col[k] = blk[lane * SB + k];   // L11(k, lane), k >= lane meaningful
+  const double rd = UNIT ? 1.0 : 1.0 / blk[lane * SB + lane];
 #pragma unroll
   for (int k = 63; k >= 0; --k) {
     if (k < nb) {
-      if (!UNIT && lane == k) yv /= col[k];
-      const double yk = __shfl(yv, k);
+      if (!UNIT && lane == k) yv *= rd;
+      const double yk = readlane_f64(yv, k);
       if (lane < k) yv -= col[k] * yk;
     }
   }
@@ -793,10 +907,32 @@ __device__ __forceinline__ double wave_trsv_bwd(const double* blk, int nb, int l
 
 __device__ __forceinline__ void stage_block(double* blk, const double* __restrict__ Lb, int ld, int b,
                                             int nb, int tid) {
-  for (int e = tid; e < 64 * 64; e += 256) {
+  double v[16];   // loads first, LDS stores afterwards (see stage_panels)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int e = tid + 256 * t;
     const int i = e & 63, k = e >> 6;
-    blk[k * SB + i] = (i < nb && k < nb && i >= k) ? Lb[int64_t(b + k) * ld + b + i] : 0.0;
+    v[t] = (i < nb && k < nb && i >= k) ? Lb[int64_t(b + k) * ld + b + i] : (i == k ? 1.0 : 0.0);
   }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int e = tid + 256 * t;
+    blk[(e >> 6) * SB + (e & 63)] = v[t];
+  }
+}
+
+// s = sum_k row[k*ld] * y[k], k < cnt <= 64, with the loads batched 16 deep
+__device__ __forceinline__ double dot_strided(const double* __restrict__ row, int64_t ld,
+                                              const double* y, int cnt) {
+  double s = 0.0;
+  for (int k0 = 0; k0 < cnt; k0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = (k0 + t < cnt) ? row[int64_t(k0 + t) * ld] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += v[t] * ((k0 + t < cnt) ? y[k0 + t] : 0.0);
+  }
+  return s;
 }
 
 // forward substitution on one front: gather children's contribution vectors, solve L11 y = rhs,
@@ -818,6 +954,7 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
   double* y = yo + n;               // n, pivot order
   const double* Lb = L + nd.loff;
   double* mine = cvec + nd.moff;
+  STAMPN(8);
   for (int i = tid; i < n; i += 256) yo[i] = xp[nd.sptr + i];
   for (int i = tid; i < cm; i += 256) mine[i] = 0.0;
   __syncthreads();
@@ -833,6 +970,7 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     }
     __syncthreads();
   }
+  STAMPN(9);
   for (int i = tid; i < n; i += 256) y[i] = POSDEF ? yo[i] : yo[gperm[nd.sptr + i] - nd.sptr];
   // blocked forward substitution
   for (int b = 0; b < n; b += 64) {
@@ -846,15 +984,10 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     }
     __syncthreads();
     // y[b+64 ..) -= L[b+64.., b..b+nb) * y[b..b+nb)
-    for (int i = b + 64 + tid; i < n; i += 256) {
-      double s = 0.0;
-      const double* row = Lb + int64_t(b) * nd.ld + i;
-#pragma unroll 8
-      for (int k = 0; k < nb; ++k) s += row[int64_t(k) * nd.ld] * y[b + k];
-      y[i] -= s;
-    }
+    for (int i = b + 64 + tid; i < n; i += 256)
+      y[i] -= dot_strided(Lb + int64_t(b) * nd.ld + i, nd.ld, y + b, nb);
   }
-  __syncthreads();
+  STAMPN(10);
   for (int i = tid; i < n; i += 256) xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]] = y[i];
   // cvec -= L21 * y : four threads per row split the columns (coalesced across rows)
   {
@@ -862,10 +995,10 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     for (int i0 = 0; i0 < cm; i0 += 64) {
       const int i = i0 + lane;
       double s = 0.0;
-      if (i < cm) {
-        const double* row = Lb + n + i;
-#pragma unroll 8
-        for (int k = q; k < n; k += 4) s += row[int64_t(k) * nd.ld] * y[k];
+      if (i < cm) {   // wave q takes the columns [q*nq, (q+1)*nq)
+        const int nq = (n + 3) / 4, kb0 = q * nq, ke0 = min(n, kb0 + nq);
+        for (int k0 = kb0; k0 < ke0; k0 += 64)
+          s += dot_strided(Lb + int64_t(k0) * nd.ld + n + i, nd.ld, y + k0, min(64, ke0 - k0));
       }
       blk[q * 64 + lane] = s;
       __syncthreads();
@@ -873,6 +1006,7 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
       __syncthreads();
     }
   }
+  STAMPN(11);
 }
 
 // x <- D^-1 x in pivot order; D holds inverted pivots, 2x2 blocks as [d11,d21,inf,d22]
@@ -905,23 +1039,53 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
   const NodeDesc nd = nodes[lvl[blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nd.n, cm = nd.m - nd.n;
-  double* blk = sh;              // 64 x SB
-  double* y = sh + 64 * SB;      // n
+  double* blk = sh;              // 64 x SB (+ 256 doubles of scratch)
+  double* y = sh + 64 * SB + 256;  // n
   double* z = y + n;             // cm
   const double* Lb = L + nd.loff;
   const int32_t* rl = rlist + nd.roff + n;
+  STAMPN(16);
   for (int i = tid; i < n; i += 256) y[i] = xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]];
   for (int i = tid; i < cm; i += 256) z[i] = xp[rl[i]];
   __syncthreads();
-  // y[k] -= sum_i L21[i,k] z[i] : one wave per column, shuffle reduction
-  for (int k = wave; k < n; k += 4) {
-    const double* col = Lb + int64_t(k) * nd.ld + n;
-    double s = 0.0;
+  STAMPN(17);
+  // y[k] -= sum_i L21[i,k] z[i]: 64 x 64 tiles of L21 go through LDS (coalesced along rows), thread
+  // (k, q) then walks 16 rows of column k out of LDS (odd stride: conflict free) -- no cross-lane
+  // reduction; the four row-quarters are combined through LDS
+  {
+    const int kc = tid & 63, q = tid >> 6;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+      double s = 0.0;
+      for (int i0 = 0; i0 < cm; i0 += 64) {
+        __syncthreads();
+        {
+          double v[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int e = tid + 256 * t;
+            const int i = e & 63, k = e >> 6;
+            v[t] = (i0 + i < cm && k0 + k < n) ? Lb[int64_t(k0 + k) * nd.ld + n + i0 + i] : 0.0;
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int e = tid + 256 * t;
+            blk[(e >> 6) * SB + (e & 63)] = v[t];
+          }
+        }
+        __syncthreads();
+        const double* zz = z + i0 + 16 * q;
+        const int lim = min(16, cm - i0 - 16 * q);
 #pragma unroll 4
-    for (int i = lane; i < cm; i += 64) s += col[i] * z[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if (lane == 0) y[k] -= s;
+        for (int i = 0; i < lim; ++i) s += blk[kc * SB + 16 * q + i] * zz[i];
+      }
+      __syncthreads();
+      blk[64 * SB + q * 64 + kc] = s;       // scratch behind the tile (blk has 64*SB + 256 doubles)
+      __syncthreads();
+      if (q == 0 && k0 + kc < n)
+        y[k0 + kc] -= (blk[64 * SB + kc] + blk[64 * SB + 64 + kc]) + (blk[64 * SB + 128 + kc] + blk[64 * SB + 192 + kc]);
+    }
   }
+  STAMPN(18);
   // blocked back substitution, last block first
   for (int b = ((n - 1) / 64) * 64; b >= 0; b -= 64) {
     const int nb = min(64, n - b);
@@ -930,6 +1094,7 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
     for (int k = b + wave; k < b + nb; k += 4) {
       const double* col = Lb + int64_t(k) * nd.ld;
       double s = 0.0;
+#pragma unroll 4
       for (int i = b + 64 + lane; i < n; i += 64) s += col[i] * y[i];
       for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
       if (lane == 0) y[k] -= s;
@@ -941,8 +1106,161 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
       if (lane < nb) y[b + lane] = v;
     }
   }
-  __syncthreads();
+  STAMPN(19);
   for (int i = tid; i < n; i += 256) xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]] = y[i];
+  STAMPN(20);
+}
+
+// =================================================================================================
+// Solve path for BIG fronts (n > BIG_N or m > BIG_M): the front does not fit one workgroup's LDS and
+// one CU cannot stream it fast enough, so every 64-column block becomes two launches -- a 64 x 64
+// triangular solve (one workgroup per front) and a GEMV over the rows below it split into 256-row
+// chunks (many workgroups per front).  y lives in HBM (ybuf, indexed by pivot slot).  Partial sums
+// of the transposed GEMV are combined in a fixed order (no atomics).
+// =================================================================================================
+struct BigTrsv {
+  int32_t node, part_first, part_cnt, pad;
+};
+struct BigGemv {
+  int32_t node, row0;
+};
+
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_big_fwd_prep(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
+               const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
+               const int32_t* __restrict__ gperm, double* __restrict__ xp, double* __restrict__ cvec,
+               double* __restrict__ ybuf) {
+  const NodeDesc nd = nodes[list[blockIdx.x]];
+  const int tid = threadIdx.x;
+  const int n = nd.n, cm = nd.m - nd.n;
+  double* mine = cvec + nd.moff;
+  for (int i = tid; i < cm; i += 256) mine[i] = 0.0;
+  __syncthreads();
+  for (int ci = nd.cbeg; ci < nd.cend; ++ci) {
+    const NodeDesc cn = nodes[clist[ci]];
+    const int ccm = cn.m - cn.n;
+    const int32_t* map = cmap + cn.moff;
+    const double* cv = cvec + cn.moff;
+    for (int i = tid; i < ccm; i += 256) {
+      const int idx = map[i];
+      if (idx < n) xp[nd.sptr + idx] += cv[i];
+      else mine[idx - n] += cv[i];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 256) ybuf[nd.sptr + i] = xp[POSDEF ? nd.sptr + i : gperm[nd.sptr + i]];
+}
+
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_big_store(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
+            const int32_t* __restrict__ gperm, const double* __restrict__ ybuf,
+            double* __restrict__ xp, int load) {
+  const NodeDesc nd = nodes[list[blockIdx.x]];
+  for (int i = threadIdx.x; i < nd.n; i += 256) {
+    const int g = POSDEF ? nd.sptr + i : gperm[nd.sptr + i];
+    if (load) const_cast<double*>(ybuf)[nd.sptr + i] = xp[g];
+    else xp[g] = ybuf[nd.sptr + i];
+  }
+}
+
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_big_fwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ tasks, int b,
+               const double* __restrict__ L, double* __restrict__ ybuf) {
+  __shared__ double blk[64 * SB];
+  const NodeDesc nd = nodes[tasks[blockIdx.x].node];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nb = min(64, nd.n - b);
+  stage_block(blk, L + nd.loff, nd.ld, b, nb, tid);
+  __syncthreads();
+  if (tid < 64) {
+    const double v = wave_trsv_fwd<!POSDEF>(blk, nb, lane, (lane < nb) ? ybuf[nd.sptr + b + lane] : 0.0);
+    if (lane < nb) ybuf[nd.sptr + b + lane] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_big_fwd_gemv(const NodeDesc* __restrict__ nodes, const BigGemv* __restrict__ tasks, int b,
+               const double* __restrict__ L, double* __restrict__ ybuf, double* __restrict__ cvec) {
+  __shared__ double ys[64];
+  const BigGemv t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x;
+  const int nb = min(64, nd.n - b);
+  if (tid < 64) ys[tid] = (tid < nb) ? ybuf[nd.sptr + b + tid] : 0.0;
+  __syncthreads();
+  const int row = t.row0 + tid;
+  if (row < nd.m) {
+    const double sum = dot_strided(L + nd.loff + int64_t(b) * nd.ld + row, nd.ld, ys, nb);
+    if (row < nd.n) ybuf[nd.sptr + row] -= sum;
+    else cvec[nd.moff + row - nd.n] -= sum;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_big_bwd_gemvT(const NodeDesc* __restrict__ nodes, const BigGemv* __restrict__ tasks, int b,
+                const int32_t* __restrict__ rlist, const double* __restrict__ L,
+                const double* __restrict__ ybuf, const double* __restrict__ xp,
+                double* __restrict__ part) {
+  __shared__ double blk[64 * SB + 256];
+  __shared__ double zz[64];
+  const BigGemv t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x, kc = tid & 63, q = tid >> 6;
+  const int nb = min(64, nd.n - b);
+  const double* Lb = L + nd.loff;
+  double s = 0.0;
+  for (int i0 = t.row0; i0 < min(t.row0 + 256, nd.m); i0 += 64) {
+    __syncthreads();
+    {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u;
+        const int i = e & 63, k = e >> 6;
+        v[u] = (i0 + i < nd.m && k < nb) ? Lb[int64_t(b + k) * nd.ld + i0 + i] : 0.0;
+      }
+      if (tid < 64) {
+        const int row = i0 + tid;
+        zz[tid] = (row >= nd.m) ? 0.0 : (row < nd.n ? ybuf[nd.sptr + row] : xp[rlist[nd.roff + row]]);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u;
+        blk[(e >> 6) * SB + (e & 63)] = v[u];
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) s += blk[kc * SB + 16 * q + i] * zz[16 * q + i];
+  }
+  __syncthreads();
+  blk[64 * SB + q * 64 + kc] = s;
+  __syncthreads();
+  if (q == 0)
+    part[int64_t(blockIdx.x) * 64 + kc] =
+        (blk[64 * SB + kc] + blk[64 * SB + 64 + kc]) + (blk[64 * SB + 128 + kc] + blk[64 * SB + 192 + kc]);
+}
+
+template <bool POSDEF>
+__global__ void __launch_bounds__(256)
+k_big_bwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ tasks, int b,
+               const double* __restrict__ L, double* __restrict__ ybuf, const double* __restrict__ part) {
+  __shared__ double blk[64 * SB];
+  const BigTrsv t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nb = min(64, nd.n - b);
+  stage_block(blk, L + nd.loff, nd.ld, b, nb, tid);
+  __syncthreads();
+  if (tid < 64) {
+    double yv = (lane < nb) ? ybuf[nd.sptr + b + lane] : 0.0;
+    for (int c = 0; c < t.part_cnt; ++c) yv -= part[int64_t(t.part_first + c) * 64 + lane];   // fixed order
+    const double v = wave_trsv_bwd<!POSDEF>(blk, nb, lane, (lane < nb) ? yv : 0.0);
+    if (lane < nb) ybuf[nd.sptr + b + lane] = v;
+  }
 }
 
 __global__ void k_iota(int n, int32_t* __restrict__ a) {
@@ -970,7 +1288,8 @@ extern "C" void gsls_debug_stamps(unsigned long long* out) {
 void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
-                  F.xhost, F.stat, F.gperm, F.asmtasks, F.faillist};
+                  F.xhost, F.stat, F.gperm, F.asmtasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
+                  F.biggemv, F.ybuf, F.part};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -1029,6 +1348,10 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<TileTask> tt;
   std::vector<int32_t> asmn;
   std::vector<AsmTask> at;
+  std::vector<int32_t> smalln, bign;
+  std::vector<BigTrsv> btr;
+  std::vector<BigGemv> bgm;
+  int64_t part_max = 0;
   F.plan.assign(S.nlevels, LevelPlan());
   for (int l = 0; l < S.nlevels; ++l) {
     LevelPlan& lp = F.plan[l];
@@ -1084,6 +1407,45 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       if (S.cptr[s + 1] - S.cptr[s] > ASM_RANKS) asmn.push_back(s);
     }
     lp.asm_cnt = int(asmn.size()) - lp.asm_begin;
+    // solve: small fronts (one workgroup each) and big fronts (blocked multi-launch path)
+    lp.small_begin = int(smalln.size());
+    lp.big_begin = int(bign.size());
+    lp.small_maxn = lp.small_maxm = 0;
+    int big_maxn = 0;
+    for (int i = lp.node_begin; i < lp.node_end; ++i) {
+      const int s = S.lvlnodes[i];
+      if (S.ncol(s) > BIG_N || S.nrow(s) > BIG_M) {
+        bign.push_back(s);
+        big_maxn = std::max(big_maxn, S.ncol(s));
+      } else {
+        smalln.push_back(s);
+        lp.small_maxn = std::max(lp.small_maxn, S.ncol(s));
+        lp.small_maxm = std::max(lp.small_maxm, S.nrow(s));
+      }
+    }
+    lp.small_cnt = int(smalln.size()) - lp.small_begin;
+    lp.big_cnt = int(bign.size()) - lp.big_begin;
+    lp.bigsteps.clear();
+    for (int b = 0; b < big_maxn; b += 64) {
+      BigStep bs;
+      bs.b = b;
+      bs.trsv_begin = int(btr.size());
+      bs.gemv_begin = int(bgm.size());
+      for (int i = lp.big_begin; i < lp.big_begin + lp.big_cnt; ++i) {
+        const int s = bign[i];
+        if (S.ncol(s) <= b) continue;
+        BigTrsv t{s, int(bgm.size()) - bs.gemv_begin, 0, 0};
+        for (int r0 = b + std::min(64, S.ncol(s) - b); r0 < S.nrow(s); r0 += 256) {
+          bgm.push_back(BigGemv{s, r0});
+          t.part_cnt++;
+        }
+        btr.push_back(t);
+      }
+      bs.trsv_cnt = int(btr.size()) - bs.trsv_begin;
+      bs.gemv_cnt = int(bgm.size()) - bs.gemv_begin;
+      part_max = std::max<int64_t>(part_max, bs.gemv_cnt);
+      lp.bigsteps.push_back(bs);
+    }
   }
 
   HIPCHK(upload(F.nodes, nd, st));
@@ -1092,6 +1454,18 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(upload(F.clist, S.clist, st));
   HIPCHK(upload(F.lvlnodes, S.lvlnodes, st));
   HIPCHK(upload(F.asmnodes, asmn, st));
+  HIPCHK(upload(F.smallnodes, smalln, st));
+  HIPCHK(upload(F.bignodes, bign, st));
+  {
+    BigTrsv* d1 = nullptr;
+    BigGemv* d2 = nullptr;
+    HIPCHK(upload(d1, btr, st));
+    HIPCHK(upload(d2, bgm, st));
+    F.bigtrsv = d1;
+    F.biggemv = d2;
+  }
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.ybuf), std::max(S.n, 1) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.part), std::max<int64_t>(part_max, 1) * 64 * sizeof(double)));
   {
     AsmTask* d = nullptr;
     HIPCHK(upload(d, at, st));
@@ -1180,15 +1554,29 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
                                    job == GSLS_SOLVE_JOB_DIAG_BWD);
   const bool do_bwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD ||
                        job == GSLS_SOLVE_JOB_DIAG_BWD);
+  const BigTrsv* btr = static_cast<const BigTrsv*>(F.bigtrsv);
+  const BigGemv* bgm = static_cast<const BigGemv*>(F.biggemv);
   if (ev) HIPCHK(hipEventRecord(ev[0], st));
   if (do_fwd)
     for (int l = 0; l < S.nlevels; ++l) {
       const LevelPlan& lp = F.plan[l];
-      int maxn = 0;
-      for (int i = lp.node_begin; i < lp.node_end; ++i) maxn = std::max(maxn, S.ncol(S.lvlnodes[i]));
-      hipLaunchKernelGGL(k_solve_fwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
-                         sizeof(double) * (64 * 65 + 2 * std::max(maxn, 1)), st, F.nodes,
-                         F.lvlnodes + lp.node_begin, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+      if (lp.small_cnt > 0)
+        hipLaunchKernelGGL(k_solve_fwd<POSDEF>, dim3(lp.small_cnt), dim3(256),
+                           sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
+                           F.smallnodes + lp.small_begin, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+      if (lp.big_cnt > 0) {
+        hipLaunchKernelGGL(k_big_fwd_prep<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.clist, F.cmap, F.gperm, xp, F.cvec, F.ybuf);
+        for (const BigStep& bs : lp.bigsteps) {
+          hipLaunchKernelGGL(k_big_fwd_trsv<POSDEF>, dim3(bs.trsv_cnt), dim3(256), 0, st, F.nodes,
+                             btr + bs.trsv_begin, bs.b, F.L, F.ybuf);
+          if (bs.gemv_cnt > 0)
+            hipLaunchKernelGGL(k_big_fwd_gemv, dim3(bs.gemv_cnt), dim3(256), 0, st, F.nodes,
+                               bgm + bs.gemv_begin, bs.b, F.L, F.ybuf, F.cvec);
+        }
+        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 0);
+      }
     }
   if (ev) HIPCHK(hipEventRecord(ev[1], st));
   if (do_diag)
@@ -1197,11 +1585,24 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
   if (do_bwd)
     for (int l = S.nlevels - 1; l >= 0; --l) {
       const LevelPlan& lp = F.plan[l];
-      int maxm = 0;
-      for (int i = lp.node_begin; i < lp.node_end; ++i) maxm = std::max(maxm, S.nrow(S.lvlnodes[i]));
-      hipLaunchKernelGGL(k_solve_bwd<POSDEF>, dim3(lp.node_end - lp.node_begin), dim3(256),
-                         sizeof(double) * (64 * 65 + std::max(maxm, 1)), st, F.nodes,
-                         F.lvlnodes + lp.node_begin, F.rlist, F.gperm, F.L, xp);
+      if (lp.big_cnt > 0) {
+        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 1);
+        for (int k = int(lp.bigsteps.size()) - 1; k >= 0; --k) {
+          const BigStep& bs = lp.bigsteps[k];
+          if (bs.gemv_cnt > 0)
+            hipLaunchKernelGGL(k_big_bwd_gemvT, dim3(bs.gemv_cnt), dim3(256), 0, st, F.nodes,
+                               bgm + bs.gemv_begin, bs.b, F.rlist, F.L, F.ybuf, xp, F.part);
+          hipLaunchKernelGGL(k_big_bwd_trsv<POSDEF>, dim3(bs.trsv_cnt), dim3(256), 0, st, F.nodes,
+                             btr + bs.trsv_begin, bs.b, F.L, F.ybuf, F.part);
+        }
+        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 0);
+      }
+      if (lp.small_cnt > 0)
+        hipLaunchKernelGGL(k_solve_bwd<POSDEF>, dim3(lp.small_cnt), dim3(256),
+                           sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,
+                           F.smallnodes + lp.small_begin, F.rlist, F.gperm, F.L, xp);
     }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));
   return hipGetLastError();

@@ -12,6 +12,8 @@ namespace gsls {
 constexpr int NB = 64;   // block-column width of the panel factorization
 constexpr int RB = 64;   // row-chunk height handled by one workgroup
 constexpr int TS = 64;   // contribution-block tile edge
+constexpr int BIG_N = 256;    // fronts wider / taller than this use the blocked multi-launch solve
+constexpr int BIG_M = 4096;
 constexpr int FAILCAP = 16384;  // capacity of the failed-pivot report of one factorization pass
 constexpr int ASM_RANKS = 4;  // children of a parent assembled by tiled launches (one per rank)
 
@@ -35,12 +37,19 @@ struct TileTask {
   int32_t node, ti, tj, pad;
 };
 
+struct BigStep {
+  int b, trsv_begin, trsv_cnt, gemv_begin, gemv_cnt;
+};
+
 struct LevelPlan {
   int node_begin, node_end;                 // range in lvlnodes
   std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
   int tile_begin, tile_cnt;                 // range in the TileTask array
   int asm_begin, asm_cnt;                   // parents with > ASM_RANKS children: range in asm node list
   int asmt_begin[ASM_RANKS], asmt_cnt[ASM_RANKS];   // tiled extend-add tasks per child rank
+  int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
+  int big_begin, big_cnt;                                // solve: blocked multi-launch fronts
+  std::vector<BigStep> bigsteps;
 };
 
 struct DeviceFactor {
@@ -52,6 +61,12 @@ struct DeviceFactor {
   int32_t* lvlnodes = nullptr;
   int32_t* asmnodes = nullptr;
   void* asmtasks = nullptr;
+  int32_t* smallnodes = nullptr;
+  int32_t* bignodes = nullptr;
+  void* bigtrsv = nullptr;
+  void* biggemv = nullptr;
+  double* ybuf = nullptr;      // y of the big-front solve path, by pivot slot
+  double* part = nullptr;      // partial sums of the transposed GEMV (64 per task)
   int64_t* asrc = nullptr;     // A -> L scatter: source index in val
   int64_t* adst = nullptr;     //                 destination element in L
   int32_t* arow = nullptr;     // pivot positions (row, col) of each scattered entry, for scaling

@@ -150,9 +150,11 @@ class SLS:
         if not self.handle:
             lib.gsls_create(C.byref(self.handle))
         self.must_be_definite = False
-        # the solver-specific defaults of SLS_initialize (sls.f90:887-892 for ssids)
+        # the solver-specific defaults of SLS_initialize (sls.f90:887-892 for ssids): own ordering, no
+        # scaling, and wider supernodes than the CPU default of 32 (fewer, fatter fronts suit the GPU)
         control.ordering = -1
         control.scaling = 0
+        control.node_amalgamation = 64
 
     # -- SLS_coord_to_sorted_csr (sls.f90:8409-8578) -----------------------------------------------
     @staticmethod

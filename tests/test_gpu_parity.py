@@ -270,6 +270,41 @@ def test_cfg4_grid_indefinite_and_shifted_posdef():
     s.terminate()
 
 
+def test_big_fronts_blocked_solve_path():
+    """3-D grids give fronts of thousands of columns: the blocked multi-launch solve path (fronts wider
+    than 256 columns) against the small-front path's answer on the same system, SPD and indefinite,
+    full and partial solves, two right-hand sides."""
+    prob = P.grid3d(30, 30, 30)
+    n, row, col, val, rhs, xs = prob
+    for posdef in (True, False):
+        s, m, c, i = run_gsls(prob, posdef, ordering_free=True)
+        assert i.status == 0 and i.max_front_size > 256      # exercises the big-front kernels
+        X = s.solve(m, np.column_stack([rhs, -2.0 * rhs]), c, i)
+        assert P.scaled_residual(n, row, col, val, X[:, 0], rhs) <= 1e-13
+        assert np.abs(X[:, 1] + 2.0 * X[:, 0]).max() <= 1e-12
+        y = s.part_solve("L", rhs, c, i)
+        if not posdef:
+            y = s.part_solve("D", y, c, i)
+        y = s.part_solve("U", y, c, i)
+        assert np.abs(y - X[:, 0]).max() <= 1e-12
+        s.terminate()
+
+
+def test_cfg5_shape_3d_grid_2M():
+    """BASELINE.json configs[4] shape on ONE GPU: 3-D stencil on a 126^3 grid, n = 2 000 376
+    (nnz(L) ~ 1.8e9, ~12.5 TFlop): residual bar and solve(A z) == z round trip."""
+    prob = P.grid3d(126, 126, 126)
+    n, row, col, val, rhs, xs = prob
+    s, m, c, i = run_gsls(prob, True, ordering_free=True)
+    assert i.status == 0, i.gsls_inform
+    x = s.solve(m, rhs, c, i)
+    assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-13
+    z = np.random.default_rng(3).uniform(-1, 1, n)
+    back = s.solve(m, P.sym_matvec(n, row - 1, col - 1, val, z), c, i)
+    assert np.abs(back - z).max() <= 1e-10
+    s.terminate()
+
+
 def test_free_ordering_matches_natural_solution():
     prob = P.grid2d(60, 60)
     s1, m, c1, i1 = run_gsls(prob, True)
