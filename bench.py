@@ -172,6 +172,13 @@ def main():
         solve_bytes = 2 * 8 * nnzL + 4 * 8 * n
         t_sweep = float(np.mean(ksolve))
         achieved = solve_bytes / t_sweep / 1e9
+        # HBM bytes of one solve sweep from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+        # collected separately with rocprofv3 --pmc and committed; only valid for the profiled config
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_cfg2.json")
+        if os.path.exists(pmc) and a.n == 100000 and a.semibw == 127 and a.ordering == "free" and a.nemin == 0:
+            with open(pmc) as f:
+                traffic = json.load(f)["solve_sweep"]["hbm_bytes_corrected"]
         out = {
             "metric": "SLS factorize+solve GF/s (fp64)", "value": value, "unit": "GF/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -185,7 +192,7 @@ def main():
                        "analyse_s": t_analyse, "scaled_residual": res},
             "roofline": {"bound": "hbm", "kernel": "triangular solve sweep (fwd+diag+bwd kernels)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": solve_bytes, "seconds_per_launch": t_sweep},
         }
         if world == 1 and not a.no_cpu_baseline:

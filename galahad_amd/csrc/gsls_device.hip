@@ -296,57 +296,75 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   }
   __syncthreads();
 
-  // ---- right-looking Cholesky of the 128 x w panel, register resident.  Thread (c, q) owns rows
-  // [32q, 32q+32) of column c, so every register index below is static while j stays a run-time
-  // loop (a fully unrolled 64-step body is ~125 KB of code and becomes instruction-fetch bound).
-  // Per eliminated column: its four owners publish it to LDS, one barrier, everybody applies the
-  // rank-1 update to its own column from LDS broadcasts.
-  STAMP(2);
-  const int c = tid & 63, q = tid >> 6;
-  double a[32];
+  // ---- right-looking Cholesky of the 128 x w panel in LDS, two-level blocked.  Columns are kept
+  // UNscaled (a = l * sqrt(d)) until the final store, so neither sqrt nor a column scaling sits on the
+  // per-pivot critical path.  Micro-panels of 8 columns live in registers -- thread (r, h) owns row r
+  // of four of them, static register indices because the 8-pivot body is unrolled -- and each pivot
+  // costs one LDS column broadcast, one barrier, one reciprocal and <= 4 FMAs per thread; the other
+  // columns take one rank-8 update per micro-panel instead of eight rank-1 updates.
+  __shared__ double colb[8][PR];
+  __shared__ double fcol[8][NB];
+  __shared__ double rdv[8];
+  __shared__ double dpv[NB];
+  const int r = tid & (PR - 1), h = tid >> 7;
+  bool failed = false;
+  for (int jb = 0; jb < w; jb += 8) {
+    const int mb = min(8, w - jb);
+    double m4[4];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) a[i] = P[c * LDP + 32 * q + i];
-  __syncthreads();
-  STAMP(3);
-  double* colbuf = P;            // 2 x PR doubles, double buffered (the panel now lives in registers)
-  double* dpiv = P + 2 * PR;     // the w pivots d_j; columns stay UNscaled (a = l * sqrt(d)) until the end,
-  bool failed = false;           // which keeps sqrt and the owner's scaling off the per-pivot critical path
-  for (int j = 0; j < w; ++j) {
-    double* cb = colbuf + (j & 1) * PR;
-    if (c == j) {
+    for (int k = 0; k < 4; ++k) m4[k] = (jb + 4 * h + k < NB) ? P[(jb + 4 * h + k) * LDP + r] : 0.0;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) cb[32 * q + i] = a[i];
+    for (int jj = 0; jj < 8; ++jj) {
+      if (jj < mb) {
+        if (h == (jj >> 2)) colb[jj][r] = m4[jj & 3];
+        __syncthreads();
+        const double d = colb[jj][jb + jj];
+        if (!(d > 0.0)) {
+          if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + jb + jj);
+          failed = true;
+        }
+        double rd = __builtin_amdgcn_rcp(d);        // reciprocal + two Newton steps: full precision
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        if (tid == 0) { rdv[jj] = rd; dpv[jb + jj] = d; }
+        const double lr = colb[jj][r] * rd;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * h + k > jj) m4[k] -= lr * colb[jj][jb + 4 * h + k];
+      }
     }
     __syncthreads();
-    const double d = cb[j];
-    if (!(d > 0.0)) {
-      if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + j);
-      failed = true;
+    // multipliers of the trailing columns, and the finished micro-panel back to the LDS panel
+    for (int e = tid; e < 8 * NB; e += 256) {
+      const int jj = e >> 6, c2 = e & 63;
+      fcol[jj][c2] = (jj < mb && c2 >= jb + 8 && c2 < w) ? colb[jj][c2] * rdv[jj] : 0.0;
     }
-    if (tid == 0) dpiv[j] = d;
-    if (c > j) {
-      const double f = cb[c] / d;            // a(c,j) / d_j
-#pragma unroll
-      for (int i = 0; i < 32; ++i) a[i] -= cb[32 * q + i] * f;
+    for (int e = tid; e < 8 * PR; e += 256) {
+      const int jj = e >> 7, rr = e & (PR - 1);
+      if (jj < mb) P[(jb + jj) * LDP + rr] = colb[jj][rr];
     }
-  }
-  __syncthreads();
-  {
-    const double dc = (c < w) ? dpiv[c] : 1.0;
-    const double s = sqrt(dc), is = 1.0 / s;
+    __syncthreads();
+    if (jb + 8 < w) {
+      double lrow[8];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) a[i] = (32 * q + i == c) ? s : a[i] * is;
-  }
-  __syncthreads();
-  // ---- back through LDS so that the store to HBM is coalesced along rows -----------------------------
+      for (int jj = 0; jj < 8; ++jj) lrow[jj] = (jj < mb) ? colb[jj][r] : 0.0;
+      for (int c2 = jb + 8 + h; c2 < w; c2 += 2) {
+        double acc2 = P[c2 * LDP + r];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) P[c * LDP + 32 * q + i] = a[i];
+        for (int jj = 0; jj < 8; ++jj) acc2 -= lrow[jj] * fcol[jj][c2];
+        P[c2 * LDP + r] = acc2;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- scale by 1/sqrt(d) on the way out; the store to HBM is coalesced along rows ------------------
+  if (tid < w) fcol[0][tid] = sqrt(dpv[tid]);
   __syncthreads();
   for (int e = tid; e < pr * w; e += 256) {
     const int row = e % pr, col = e / pr;
-    if (row >= col) Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row];
+    if (row > col) Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row] / fcol[0][col];
+    else if (row == col) Lb[int64_t(kb + col) * nd.ld + kb + row] = fcol[0][col];
   }
-  STAMP(5);
 }
 
 // ---- LDL^T flavour: complete pivoting (1x1 and 2x2) inside the w x w diagonal block, applied to the

@@ -14,6 +14,7 @@
 //   leaves are numbered in breadth-first order (a reverse Cuthill-McKee flavour: small bandwidth,
 //   so leaf fronts stay narrow).
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include "gsls_internal.hpp"
@@ -74,7 +75,8 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
   perm.assign(n, -1);
   if (n == 0) return;
   Work w(aptr, arow, n);
-  const int leaf_size = 384;
+  int leaf_size = 128;
+  if (const char* e = std::getenv("GSLS_ND_LEAF")) leaf_size = std::max(8, std::atoi(e));   // tuning knob
 
   struct Sub {
     std::vector<int> verts;
