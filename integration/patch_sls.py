@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Produces a copy of GALAHAD's src/sls/sls.f90 with the `gsls` backend arms of INTEGRATION.md
+inserted, so that the REAL SLS facade can be built against the MI355X backend and driven end to end
+(tests/test_sls_dropin.py).  The reference source is read where it lies and the patched copy is
+written to the path given on the command line (a scratch directory -- never the repository).
+
+The repository holds only what a maintainer would add: the arms below.  Each arm is inserted in
+front of the k-th `CASE ( 'ssids' )` of the file, the arm it mirrors (src/sls/sls.f90 line numbers of
+the v4.0 tree in the comments), and 'gsls' joins the three shared CASE lists.
+"""
+import re
+import sys
+
+ARMS = [
+    # 0: SLS_initialize, solver-specific defaults (ssids arm :887-892)
+    """     CASE ( 'gsls' )
+       CALL GSLS_initialize( data%gsls_keep, data%gsls_options )
+       control%scaling = 0
+       IF ( control%ordering == 0 ) control%ordering = - 1
+       control%node_amalgamation = 64
+
+""",
+    # 1: SLS_initialize_solver (:1024)
+    """     CASE ( 'gsls' )
+       data%must_be_definite = .FALSE.
+
+""",
+    # 2: SLS_analyse (:3115-3150)
+    """       CASE ( 'gsls' )
+         CALL SLS_copy_control_to_gsls( control, data%gsls_options )
+         CALL CPU_time( time ) ; CALL CLOCK_time( clock )
+         IF ( PRESENT( PERM ) .OR. mc6168_ordering ) THEN
+           data%gsls_options%ordering = 0
+         ELSE IF ( control%ordering < 0 ) THEN
+           data%gsls_options%ordering = 1
+         ELSE
+           data%gsls_options%ordering = 3
+         END IF
+         IF ( ALLOCATED( data%gsls_ptr ) ) THEN
+           IF ( SIZE( data%gsls_ptr ) < matrix%n + 1 ) DEALLOCATE( data%gsls_ptr )
+         END IF
+         IF ( .NOT. ALLOCATED( data%gsls_ptr ) )                                &
+           ALLOCATE( data%gsls_ptr( matrix%n + 1 ), STAT = inform%alloc_status )
+         IF ( inform%alloc_status /= 0 ) THEN
+           inform%status = GALAHAD_error_allocate ; GO TO 900 ; END IF
+         data%gsls_ptr( : matrix%n + 1 ) = data%matrix%PTR( : matrix%n + 1 )
+         CALL GSLS_analyse( data%matrix%n, data%gsls_ptr, data%matrix%COL,      &
+                            data%gsls_keep, data%gsls_options,                  &
+                            data%gsls_inform, data%ORDER )
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+         IF ( inform%status /= GALAHAD_ok ) GO TO 800
+
+""",
+    # 3: SLS_factorize (:4273-4297)
+    """       CASE ( 'gsls' )
+         CALL SLS_copy_control_to_gsls( control, data%gsls_options )
+         CALL CPU_time( time ) ; CALL CLOCK_time( clock )
+         CALL GSLS_factor( data%must_be_definite, data%matrix%VAL,              &
+                           data%gsls_keep, data%gsls_options, data%gsls_inform )
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+
+""",
+    # 4: SLS_solve_one_rhs (:5392-5397)
+    """     CASE ( 'gsls' )
+       CALL CPU_time( time ) ; CALL CLOCK_time( clock )
+       CALL GSLS_solve( X( : data%n ), data%gsls_keep, data%gsls_options,       &
+                        data%gsls_inform )
+       CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+
+""",
+    # 5: SLS_solve_multiple_rhs (:5693-5700)
+    """     CASE ( 'gsls' )
+       lx = SIZE( X, 1 ) ; nrhs = SIZE( X, 2 )
+       CALL CPU_time( time ) ; CALL CLOCK_time( clock )
+       CALL GSLS_solve_mult( nrhs, X, lx, data%gsls_keep, data%gsls_options,    &
+                             data%gsls_inform )
+       CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+
+""",
+    # 6: SLS_terminate (:5972-5974)
+    """     CASE ( 'gsls' )
+       CALL SPACE_dealloc_array( data%X2, inform%status, inform%alloc_status )
+       CALL GSLS_free( data%gsls_keep, inform%status )
+       inform%status = 0
+
+""",
+    # 7: SLS_enquire (:6312-6345)
+    """     CASE ( 'gsls' )
+       IF ( PRESENT( PERM ) ) PERM = data%ORDER( : data%n )
+       IF ( PRESENT( PERTURBATION ) ) inform%status = GALAHAD_error_access_pert
+       IF ( data%must_be_definite ) THEN
+         IF ( PRESENT( PIVOTS ) ) inform%status = GALAHAD_error_access_pivots
+         IF ( PRESENT( D ) ) THEN
+           CALL GSLS_enquire_posdef( data%gsls_keep, data%gsls_inform, D( 1, : ) )
+           D( 2, : ) = 0.0_wp
+         END IF
+       ELSE
+         IF ( PRESENT( D ) .AND. PRESENT( PIVOTS ) ) THEN
+           CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform,           &
+                                    piv_order = PIVOTS, d = D )
+         ELSE IF ( PRESENT( D ) ) THEN
+           CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform, d = D )
+         ELSE IF ( PRESENT( PIVOTS ) ) THEN
+           CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform,           &
+                                    piv_order = PIVOTS )
+         END IF
+       END IF
+
+""",
+    # 8: SLS_alter_d (:6488-6494)
+    """     CASE ( 'gsls' )
+       IF ( data%must_be_definite ) THEN
+         inform%status = GALAHAD_ok
+       ELSE
+         CALL GSLS_alter( D, data%gsls_keep, data%gsls_inform )
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+       END IF
+
+""",
+    # 9: SLS_part_solve (:6886-6920; the ssids arm returns "unavailable", gsls implements L, D, U)
+    """     CASE ( 'gsls' )
+       CALL CPU_time( time ) ; CALL CLOCK_time( clock )
+       IF ( part == 'L' ) THEN
+         CALL GSLS_solve( X( : data%n ), data%gsls_keep, data%gsls_options,     &
+                          data%gsls_inform, job = 1 )
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+       ELSE IF ( part == 'D' ) THEN
+         IF ( data%must_be_definite ) THEN
+           inform%status = 0
+         ELSE
+           CALL GSLS_solve( X( : data%n ), data%gsls_keep, data%gsls_options,   &
+                            data%gsls_inform, job = 2 )
+           CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+         END IF
+       ELSE IF ( part == 'U' ) THEN
+         CALL GSLS_solve( X( : data%n ), data%gsls_keep, data%gsls_options,     &
+                          data%gsls_inform, job = 3 )
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+       ELSE
+         inform%status = GALAHAD_unavailable_option
+       END IF
+       GO TO 900
+
+""",
+]
+
+COPY_ROUTINES = """
+!-*-   S L S _ C O P Y _ C O N T R O L _ T O _ G S L S  S U B R O U T I N E  -*-
+
+     SUBROUTINE SLS_copy_control_to_gsls( control, control_gsls )
+
+!  copy control parameters to their GSLS equivalents (cf. SLS_copy_control_to_ssids)
+
+     TYPE ( SLS_control_type ), INTENT( IN ) :: control
+     TYPE ( gsls_options ), INTENT( INOUT ) :: control_gsls
+
+     control_gsls%print_level = control%print_level_solver - 1
+     control_gsls%nemin = control%node_amalgamation
+     control_gsls%small = control%absolute_pivot_tolerance
+     IF ( control%pivot_control == 2 .OR. control%pivot_control == 4 ) THEN
+       control_gsls%u = 0.0_wp ; control_gsls%action = 1
+     ELSE IF ( control%pivot_control == 3 ) THEN
+       control_gsls%u = 0.0_wp ; control_gsls%action = 0
+     ELSE
+       control_gsls%u = control%relative_pivot_tolerance ; control_gsls%action = 1
+     END IF
+     RETURN
+     END SUBROUTINE SLS_copy_control_to_gsls
+
+!-*-   S L S _ C O P Y _ I N F O R M _ F R O M _ G S L S  S U B R O U T I N E  -*-
+
+     SUBROUTINE SLS_copy_inform_from_gsls( inform, info_gsls )
+
+!  copy inform parameters from their GSLS equivalents (cf. SLS_copy_inform_from_ssids:
+!  the flag space is that of SSIDS, so the status mapping is the same)
+
+     TYPE ( SLS_inform_type ), INTENT( INOUT ) :: inform
+     TYPE ( gsls_inform ), INTENT( IN ) :: info_gsls
+
+     inform%status = info_gsls%flag
+     SELECT CASE( inform%status )
+     CASE ( 0 : )
+       inform%status = GALAHAD_ok
+       inform%two_by_two_pivots = info_gsls%num_two
+       inform%rank = info_gsls%matrix_rank
+       inform%negative_eigenvalues = info_gsls%num_neg
+       inform%delayed_pivots = info_gsls%num_delay
+       inform%entries_in_factors = info_gsls%num_factor
+       inform%flops_elimination = info_gsls%num_flops
+       inform%max_front_size  = info_gsls%maxfront
+       inform%max_depth_assembly_tree = info_gsls%maxdepth
+     CASE ( - 30  )
+       inform%status = GALAHAD_error_allocate
+     CASE ( - 31  )
+       inform%status = GALAHAD_error_deallocate
+     CASE( - 1, - 2, - 3, - 4, - 5, - 6, - 9, - 10, - 12, - 13, - 14, - 15 )
+       inform%status = GALAHAD_error_restrictions
+     CASE ( - 11 )
+       inform%status = GALAHAD_error_permutation
+     CASE ( - 7, - 8  )
+       inform%status = GALAHAD_error_inertia
+     CASE ( - 32, GALAHAD_unavailable_option  )
+       inform%status = GALAHAD_unavailable_option
+     CASE DEFAULT
+       inform%status = GALAHAD_error_technical
+     END SELECT
+     RETURN
+     END SUBROUTINE SLS_copy_inform_from_gsls
+
+"""
+
+
+def main(src, dst):
+    lines = open(src).read().split("\n")
+    out = []
+    k = 0
+    for ln in lines:
+        if re.fullmatch(r"\s*CASE \( 'ssids' \)", ln) and k < len(ARMS):
+            out.extend(ARMS[k].rstrip("\n").split("\n"))
+            out.append("")
+            k += 1
+        if "'ssids'" in ln and "," in ln and "CASE (" in ln and "'gsls'" not in ln:
+            ln = ln.replace("'ssids'", "'ssids', 'gsls'")          # the shared CASE lists
+        out.append(ln)
+        if ln.strip() == "USE SPRAL_SSIDS":
+            out.append("     USE GALAHAD_GSLS_double")
+        if ln.strip() == "TYPE ( SSIDS_inform ) :: ssids_inform" and "gsls_keep" not in "\n".join(out[-8:]) \
+                and any("TYPE ( SSIDS_akeep ) :: ssids_akeep" in x for x in out[-6:]):
+            out.append("       TYPE ( gsls_keep ) :: gsls_keep")
+            out.append("       TYPE ( gsls_options ) :: gsls_options")
+            out.append("       TYPE ( gsls_inform ) :: gsls_inform")
+            out.append("       INTEGER ( KIND = long ), ALLOCATABLE, DIMENSION( : ) :: gsls_ptr")
+        if ln.strip() == "END SUBROUTINE SLS_copy_inform_from_ssids":
+            out.extend(COPY_ROUTINES.split("\n"))
+    assert k == len(ARMS), "expected %d ssids arms, patched %d" % (len(ARMS), k)
+    text = "\n".join(out)
+    assert "USE GALAHAD_GSLS_double" in text and "TYPE ( gsls_keep ) :: gsls_keep" in text
+    open(dst, "w").write(text)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

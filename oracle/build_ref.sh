@@ -100,3 +100,18 @@ wait $p1 $p2 $p3
 $FC -fopenmp -shared -o $OUT/libgalahad_ref.so $W/obj/*.o -lstdc++
 $FC $FFLAGS -o $OUT/ref_driver $HERE/ref_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
 echo "build_ref: wrote $OUT/libgalahad_ref.so and $OUT/ref_driver"
+
+# ---- drop-in build: the REAL SLS facade with the gsls arms of INTEGRATION.md, linked to the MI355X
+#      backend.  The patched sls.f90 exists only in the scratch dir. ---------------------------------
+GSLS_LIB=$HERE/../galahad_amd/libgsls.so
+if [ -f "$GSLS_LIB" ]; then
+  mkdir -p $W/mod2
+  python3 $HERE/../integration/patch_sls.py $S/sls/sls.f90 $W/sls_gsls.f90
+  $FC $OPT -fPIC -module-dir $W/mod2 -c -o $W/obj2_gsls_iface.o $HERE/../galahad_amd/fortran/gsls_iface.f90
+  F2="$OPT -fopenmp -fPIC -module-dir $W/mod2 -I$W/mod2 -I$W/mod"
+  $FC $F2 -c -o $W/obj2_sls_gsls.o $W/sls_gsls.f90
+  $FC $F2 -o $OUT/sls_gsls_driver $HERE/ref_driver.f90 \
+      $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  echo "build_ref: wrote $OUT/sls_gsls_driver (GALAHAD SLS facade + gsls backend)"
+fi

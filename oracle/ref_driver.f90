@@ -9,7 +9,7 @@
 ! problem.bin (native endian, stream):
 !   int32  magic(=1397509959 'GSLS') version(=1)
 !   int32  n ne nrhs solver(0 ssids,1 sytr,2 potr,3 pbtr) pivot_control max_refine nemin
-!          have_perm repeat dump_struct scaling ordering
+!          have_perm repeat dump_struct scaling ordering   (solver 4 = gsls, drop-in build only)
 !   real64 relative_pivot_tolerance absolute_pivot_tolerance
 !   int32  row(ne) col(ne) ; real64 val(ne) ; int32 perm(n) [if have_perm] ; real64 rhs(n*nrhs)
 ! result.bin:
@@ -65,6 +65,7 @@ program gsls_ref_driver
   case (1) ; solver = 'sytr'
   case (2) ; solver = 'potr'
   case (3) ; solver = 'pbtr'
+  case (4) ; solver = 'gsls'   ! only in the drop-in build (integration/patch_sls.py)
   case default ; stop 'ref_driver: bad solver id'
   end select
 

@@ -13,11 +13,16 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DRIVER = os.path.join(HERE, "_ref", "ref_driver")
 MAGIC = 1397509959
-SOLVERS = {"ssids": 0, "sytr": 1, "potr": 2, "pbtr": 3}
+DROPIN = os.path.join(HERE, "_ref", "sls_gsls_driver")   # real SLS facade + the gsls backend
+SOLVERS = {"ssids": 0, "sytr": 1, "potr": 2, "pbtr": 3, "gsls": 4}
 
 
 def available():
     return os.path.exists(DRIVER) and os.access(DRIVER, os.X_OK)
+
+
+def dropin_available():
+    return os.path.exists(DROPIN) and os.access(DROPIN, os.X_OK)
 
 
 def write_problem(path, n, row, col, val, rhs, *, solver="ssids", pivot_control=1, max_refine=0,
@@ -102,7 +107,8 @@ def run(n, row, col, val, rhs, *, threads=None, timeout=3600, **kw):
         if threads is not None:
             env["OMP_NUM_THREADS"] = str(threads)
         # n >~ 1e6 needs an unlimited stack for SLS's automatic arrays (sls.f90:8436)
-        cmd = "ulimit -s unlimited 2>/dev/null; exec '%s' '%s' '%s'" % (DRIVER, pin, pout)
+        exe = DROPIN if kw.get("solver") == "gsls" else DRIVER
+        cmd = "ulimit -s unlimited 2>/dev/null; exec '%s' '%s' '%s'" % (exe, pin, pout)
         p = subprocess.run(["bash", "-c", cmd], env=env, capture_output=True, text=True,
                            timeout=timeout)
         if p.returncode != 0 or not os.path.exists(pout):

@@ -1,0 +1,69 @@
+"""Drop-in proof: the REAL GALAHAD SLS facade (src/sls/sls.f90 of the reference, patched at build time
+with the `CASE ( 'gsls' )` arms of INTEGRATION.md by integration/patch_sls.py) linked against the
+MI355X backend -- oracle/_ref/sls_gsls_driver, built by oracle/build_ref.sh next to the plain
+reference driver.  Callers say SLS_initialize('gsls', ...) and nothing else changes: SLS's own
+coordinate->CSR map, value scatter, iterative refinement and status mapping run unmodified.
+The binary is test infrastructure (it contains reference objects) and never ships in galahad_amd/."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def _need_dropin():
+    from oracle import refio
+    if not refio.dropin_available():
+        pytest.skip("oracle/_ref/sls_gsls_driver not built (needs /root/reference at build time)")
+    return refio
+
+
+def test_dropin_analyse_through_real_sls_and_loud_failure(have_gpu):
+    """CPU: SLS_analyse through the facade reaches gsls_analyse (same statistics as the reference's
+    ssids arm); without a device SLS_factorize reports GALAHAD_error_technical (-50), not a result."""
+    refio = _need_dropin()
+    n, row, col, val, rhs, xs = P.kat_indefinite()
+    r = refio.run(n, row, col, val, rhs, solver="gsls", perm=np.arange(1, n + 1), nemin=32)
+    assert r["status_analyse"] == 0
+    if not have_gpu:
+        assert r["status_factorize"] == -50
+    else:
+        assert r["status_factorize"] == 0 and np.abs(r["x"] - xs).max() <= 1.5e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_dropin_matches_reference_golden(path):
+    refio = _need_dropin()
+    g = np.load(path)
+    n = int(g["n"])
+    posdef = bool(g["posdef"])
+    r = refio.run(n, g["row"], g["col"], g["val"], g["rhs"], solver="gsls", perm=g["perm"],
+                  nemin=int(g["nemin"]), pivot_control=2 if posdef else 1)
+    assert (r["status_analyse"], r["status_factorize"], r["status_solve"]) == (0, 0, 0)
+    assert r["negative_eigenvalues"] == int(g["ref_neg"]) and r["rank"] == int(g["ref_rank"])
+    if r["delayed"] == 0:
+        assert r["entries_in_factors"] == int(g["ref_num_factor"])
+        assert r["flops_elimination"] == int(g["ref_num_flops"])
+    assert np.abs(r["x"] - g["ref_x"]).max() <= 1e-9 * max(1.0, np.abs(g["ref_x"]).max())
+
+
+@pytest.mark.gpu
+def test_dropin_defaults_refinement_and_not_posdef():
+    """solver-specific defaults (own ordering, no PERM), SLS's own iterative refinement loop
+    (sls.f90:4751-4963) around the backend, and the -6 -> GALAHAD_error_restrictions quirk."""
+    refio = _need_dropin()
+    prob = P.kkt_qpband(20000, 4000)
+    n, row, col, val, rhs, xs = prob
+    r = refio.run(n, row, col, val, rhs, solver="gsls", max_refine=1)
+    assert (r["status_analyse"], r["status_factorize"], r["status_solve"]) == (0, 0, 0)
+    assert r["negative_eigenvalues"] == 4000 and r["rank"] == 24000
+    assert P.scaled_residual(n, row, col, val, r["x"], rhs) <= 1e-14
+    n, row, col, val, rhs, xs = P.kat_indefinite()
+    r = refio.run(n, row, col, val, rhs, solver="gsls", pivot_control=2)
+    assert r["status_factorize"] == -3
