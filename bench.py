@@ -110,12 +110,11 @@ def main():
     s.initialize("gsls", c, inf)
     c.pivot_control = 2
     s.opts.device = local_rank
-    if a.ordering == "natural":
-        c.ordering = 0
+    perm = np.arange(1, n + 1) if a.ordering == "natural" else None
     if a.nemin > 0:
         c.node_amalgamation = a.nemin
     t0 = time.perf_counter()
-    s.analyse(m, c, inf)
+    s.analyse(m, c, inf, PERM=perm)
     t_analyse = time.perf_counter() - t0
     assert inf.status == 0, inf.status
     nnzL, flops_used = inf.entries_in_factors, inf.flops_elimination
@@ -164,8 +163,7 @@ def main():
         if F is None:   # non-default shape: natural-order flops from a second symbolic analyse
             s2, c2, i2 = SLS(), Control(), InformSLS()
             s2.initialize("gsls", c2, i2)
-            c2.ordering = 0
-            s2.analyse(m, c2, i2)
+            s2.analyse(m, c2, i2, PERM=np.arange(1, n + 1))
             F = i2.flops_elimination
             s2.terminate()
         value = world * a.steps * F / elapsed / 1e9

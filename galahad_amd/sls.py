@@ -221,9 +221,9 @@ class SLS:
             self.opts.ordering = 0
             self.ORDER = np.ascontiguousarray(PERM, dtype=np.int32).copy()
         else:
-            # ssids would call METIS for control%ordering<0 (sls.f90:3134); gsls uses its own ND;
-            # control%ordering == 0 keeps the natural order like SLS's default ORDER(i)=i
-            self.opts.ordering = 3 if control.ordering >= 0 else 1
+            # ssids would call METIS here (sls.f90:3134); gsls uses its own nested dissection for
+            # control%ordering <= 0 (SBLS reaches SLS with 0).  Natural order = PERM identity.
+            self.opts.ordering = 1
             self.ORDER = np.arange(1, n + 1, dtype=np.int32)
         ginf = Inform()
         flag = lib.gsls_analyse(self.handle, n, self.PTR.ctypes.data_as(_lib.p_i64),

@@ -6,7 +6,10 @@ written to the path given on the command line (a scratch directory -- never the 
 
 The repository holds only what a maintainer would add: the arms below.  Each arm is inserted in
 front of the k-th `CASE ( 'ssids' )` of the file, the arm it mirrors (src/sls/sls.f90 line numbers of
-the v4.0 tree in the comments), and 'gsls' joins the three shared CASE lists.
+the v4.0 tree in the comments), and 'gsls' joins the two shared CASE lists that select the sorted
+lower-by-columns storage (:2849, :4106).  It does NOT join the list at :2263: that one routes
+control%ordering >= 0 to MC68 (a stub here), whereas SBLS reaches SLS with ordering = 0 and expects
+the solver's own default ordering.
 """
 import re
 import sys
@@ -30,11 +33,9 @@ ARMS = [
          CALL SLS_copy_control_to_gsls( control, data%gsls_options )
          CALL CPU_time( time ) ; CALL CLOCK_time( clock )
          IF ( PRESENT( PERM ) .OR. mc6168_ordering ) THEN
-           data%gsls_options%ordering = 0
-         ELSE IF ( control%ordering < 0 ) THEN
-           data%gsls_options%ordering = 1
+           data%gsls_options%ordering = 0        ! use data%ORDER as given
          ELSE
-           data%gsls_options%ordering = 3
+           data%gsls_options%ordering = 1        ! built-in nested dissection (control%ordering <= 0)
          END IF
          IF ( ALLOCATED( data%gsls_ptr ) ) THEN
            IF ( SIZE( data%gsls_ptr ) < matrix%n + 1 ) DEALLOCATE( data%gsls_ptr )
@@ -219,7 +220,7 @@ def main(src, dst):
             out.extend(ARMS[k].rstrip("\n").split("\n"))
             out.append("")
             k += 1
-        if "'ssids'" in ln and "," in ln and "CASE (" in ln and "'gsls'" not in ln:
+        if "'ssids'" in ln and "'ma86'" in ln and "'ma77'" not in ln and "CASE (" in ln and "'gsls'" not in ln:
             ln = ln.replace("'ssids'", "'ssids', 'gsls'")          # the shared CASE lists
         out.append(ln)
         if ln.strip() == "USE SPRAL_SSIDS":

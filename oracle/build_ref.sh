@@ -94,11 +94,17 @@ fc dum/mkl_pardiso.f90
 fc dum/pardiso.f90
 fc dum/wsmp.f90
 fc sls/sls.f90
+# SBLS (saddle-point / KKT layer above SLS) and what it USEs; ULS/GLS only for its implicit variants
+for f in lmt/lmt.f90 qpt/qpt.f90 roots/roots.f90 norms/norms.f90 gls/gls.f90 dum/hsl_ma48d.f90 \
+         uls/uls.f90 sbls/sbls.f90 ; do fc $f ; done
+for f in dum/ma33d.f dum/mc13d.f dum/mc21d.f dum/mc22d.f dum/mc23d.f dum/mc29d.f \
+         dum/mc30d.f ; do ff $f ; done
 wait $p1 $p2 $p3
 
 # ---- link ------------------------------------------------------------------------------------------
 $FC -fopenmp -shared -o $OUT/libgalahad_ref.so $W/obj/*.o -lstdc++
 $FC $FFLAGS -o $OUT/ref_driver $HERE/ref_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
+$FC $FFLAGS -o $OUT/sbls_driver $HERE/sbls_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
 echo "build_ref: wrote $OUT/libgalahad_ref.so and $OUT/ref_driver"
 
 # ---- drop-in build: the REAL SLS facade with the gsls arms of INTEGRATION.md, linked to the MI355X
@@ -113,5 +119,10 @@ if [ -f "$GSLS_LIB" ]; then
   $FC $F2 -o $OUT/sls_gsls_driver $HERE/ref_driver.f90 \
       $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
       -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
-  echo "build_ref: wrote $OUT/sls_gsls_driver (GALAHAD SLS facade + gsls backend)"
+  # SBLS above the patched SLS (source unchanged; recompiled because SLS_data_type grew)
+  $FC $F2 -c -o $W/obj2_sbls.o $S/sbls/sbls.f90
+  $FC $F2 -o $OUT/sbls_gsls_driver $HERE/sbls_driver.f90 $W/obj2_sbls.o \
+      $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  echo "build_ref: wrote $OUT/sls_gsls_driver, $OUT/sbls_gsls_driver (GALAHAD SLS/SBLS + gsls backend)"
 fi

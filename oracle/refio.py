@@ -114,3 +114,50 @@ def run(n, row, col, val, rhs, *, threads=None, timeout=3600, **kw):
         if p.returncode != 0 or not os.path.exists(pout):
             raise RuntimeError("ref_driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
         return read_result(pout, n, nrhs, kw.get("dump_struct", False))
+
+
+SBLS_DRIVER = os.path.join(HERE, "_ref", "sbls_driver")            # reference SBLS (ssids / sytr)
+SBLS_DROPIN = os.path.join(HERE, "_ref", "sbls_gsls_driver")       # reference SBLS + SLS facade + gsls
+
+
+def sbls_available(dropin=False):
+    p = SBLS_DROPIN if dropin else SBLS_DRIVER
+    return os.path.exists(p) and os.access(p, os.X_OK)
+
+
+def run_sbls(n, m, H, A, Cm, rhs, *, solver="gsls", factorization=2, repeat=1, itref_max=1,
+             threads=None, timeout=3600, print_level=0):
+    """SBLS_form_and_factorize + SBLS_solve on K = [H A^T; A -C].  H, A, Cm = (row, col, val) with
+    1-based indices (H, C lower triangles).  Returns dict(status_factorize, status_solve, sol, ...)."""
+    exe = SBLS_DROPIN if solver == "gsls" else SBLS_DRIVER
+    if not os.path.exists(exe):
+        raise RuntimeError("%s not built" % exe)
+    with tempfile.TemporaryDirectory(prefix="gsls_sbls_") as d:
+        pin, pout = os.path.join(d, "p.bin"), os.path.join(d, "r.bin")
+        with open(pin, "wb") as f:
+            f.write(struct.pack("<2i", 1396853330, 1))
+            f.write(struct.pack("<10i", n, m, len(H[0]), len(A[0]), len(Cm[0]), SOLVERS[solver],
+                                factorization, repeat, itref_max, print_level))
+            for (r, c, v) in (H, A, Cm):
+                f.write(np.ascontiguousarray(r, dtype=np.int32).tobytes())
+                f.write(np.ascontiguousarray(c, dtype=np.int32).tobytes())
+                f.write(np.ascontiguousarray(v, dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(rhs, dtype=np.float64).tobytes())
+        env = dict(os.environ)
+        env["OMP_CANCELLATION"] = "true"
+        if threads is not None:
+            env["OMP_NUM_THREADS"] = str(threads)
+        cmd = "ulimit -s unlimited 2>/dev/null; exec '%s' '%s' '%s'" % (exe, pin, pout)
+        p = subprocess.run(["bash", "-c", cmd], env=env, capture_output=True, text=True, timeout=timeout)
+        if p.returncode != 0 or not os.path.exists(pout):
+            raise RuntimeError("sbls driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
+        if print_level:
+            print(p.stdout)
+        buf = open(pout, "rb").read()
+        ints = np.frombuffer(buf, dtype="<i4", count=6)
+        tms = np.frombuffer(buf, dtype="<f8", count=4, offset=24)
+        sol = np.frombuffer(buf, dtype="<f8", count=n + m, offset=24 + 32).copy()
+        return dict(status_factorize=int(ints[0]), status_solve=int(ints[1]), factorization=int(ints[2]),
+                    rank=int(ints[3]), negative_eigenvalues=int(ints[4]), t_factorize=float(tms[0]),
+                    t_solve=float(tms[1]), t_factorize_median=float(tms[2]), t_solve_median=float(tms[3]),
+                    sol=sol)

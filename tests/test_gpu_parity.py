@@ -39,7 +39,7 @@ def run_gsls(prob, posdef, perm=None, nemin=32, refine=0, ordering_free=False, s
     c.node_amalgamation = nemin
     c.max_iterative_refinements = refine
     if perm is None and not ordering_free:
-        c.ordering = 0
+        perm = np.arange(1, n + 1)         # natural order = identity PERM (ordering <= 0 means own ND)
     s.analyse(m, c, i, PERM=perm)
     assert i.status == 0, i.status
     s.factorize(m, c, i)

@@ -1,0 +1,108 @@
+"""SBLS row of the scope table: the reference's SBLS_form_and_factorize / SBLS_solve
+(src/sbls/sbls.f90:1695-1903, 4937-5388) -- unchanged source, built above the patched SLS facade --
+with control%symmetric_linear_solver = 'gsls'.  SBLS assembles K = [H A^T; A -C] in COORDINATE form,
+analyses/factorizes through SLS, checks the inertia itself (exactly m negative eigenvalues,
+sbls.f90:4166-4224) and refines the solve; all of that is the reference's own Fortran, only the
+factorize+solve underneath runs on the MI355X.
+
+The reference's own CPU path cannot be timed beside it here: SBLS passes no PERM, and the orderings
+SLS would call for ssids (METIS / MC68) are stubs in the tree -- so parity for SBLS is
+pinned by the package's own known answer (src/sbls/sblss.f90 + sblsds.output: solution all ones) and
+by constructed solutions."""
+import numpy as np
+import pytest
+
+import problems as P
+
+
+def _need():
+    from oracle import refio
+    if not refio.sbls_available(dropin=True):
+        pytest.skip("oracle/_ref/sbls_gsls_driver not built (needs /root/reference at build time)")
+    return refio
+
+
+SBLSS = dict(n=3, m=2, H=([1, 2, 3, 3], [1, 2, 3, 1], [1.0, 2.0, 3.0, 4.0]),
+             A=([1, 1, 2, 2], [1, 2, 2, 3], [2.0, 1.0, 1.0, 1.0]), C=([2], [1], [1.0]),
+             rhs=[7.0, 4.0, 8.0, 2.0, 1.0])                     # src/sbls/sblss.f90:13-29
+
+
+def test_sbls_reaches_backend_and_fails_loudly_without_gpu(have_gpu):
+    refio = _need()
+    k = SBLSS
+    r = refio.run_sbls(k["n"], k["m"], k["H"], k["A"], k["C"], k["rhs"], solver="gsls")
+    if have_gpu:
+        assert r["status_factorize"] == 0
+    else:
+        assert r["status_factorize"] == -10          # GALAHAD_error_factorization, no fake result
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factorization", [0, 1, 2])
+def test_sbls_spec_sheet_example(factorization):
+    """src/sbls/sblss.f90 / sblsds.output: ' SBLS: Solution = 1.0 1.0 1.0 1.0 1.0' for the automatic
+    choice, the Schur-complement and the augmented-system factorizations."""
+    refio = _need()
+    k = SBLSS
+    r = refio.run_sbls(k["n"], k["m"], k["H"], k["A"], k["C"], k["rhs"], solver="gsls",
+                       factorization=factorization)
+    assert (r["status_factorize"], r["status_solve"]) == (0, 0)
+    assert np.abs(r["sol"] - 1.0).max() <= 1e-12
+
+
+def _qp_kkt(n, m, seed):
+    """cfg3 generator split into the H, A, C that SBLS wants (tests/problems.py:kkt_qpband)."""
+    rng = np.random.default_rng(seed)
+    sigma = 10.0 ** rng.uniform(-4, 4, n)
+    i = np.arange(1, n + 1)
+    H = (np.concatenate([i, i[1:]]), np.concatenate([i, i[:-1]]),
+         np.concatenate([2.0 + sigma, np.full(n - 1, -1.0)]))
+    j = np.arange(1, m + 1)
+    A = (np.concatenate([j, j]), np.concatenate([j, m + j]), np.ones(2 * m))
+    C = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    return H, A, C
+
+
+def _kkt_rhs(n, m, H, A, x, y):
+    """[H A^T; A 0] [x; y]"""
+    r = np.zeros(n + m)
+    hr, hc, hv = H[0] - 1, H[1] - 1, H[2]
+    np.add.at(r, hr, hv * x[hc])
+    off = hr != hc
+    np.add.at(r, hc[off], hv[off] * x[hr[off]])
+    ar, ac, av = A[0] - 1, A[1] - 1, A[2]
+    np.add.at(r, ac, av * y[ar])
+    np.add.at(r, n + ar, av * x[ac])
+    return r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(2000, 400), (100000, 20000)])
+def test_sbls_kkt_constructed_solution(n, m):
+    refio = _need()
+    H, A, C = _qp_kkt(n, m, 20240102)
+    rng = np.random.default_rng(7)
+    x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+    rhs = _kkt_rhs(n, m, H, A, x, y)
+    r = refio.run_sbls(n, m, H, A, C, rhs, solver="gsls", factorization=2, repeat=2)
+    assert (r["status_factorize"], r["status_solve"]) == (0, 0)
+    assert r["negative_eigenvalues"] == m                       # SBLS's own inertia requirement
+    err = np.abs(r["sol"] - np.concatenate([x, y])).max()
+    assert err <= 1e-8, err
+
+
+@pytest.mark.gpu
+def test_sbls_cfg3_full_size():
+    """BASELINE.json configs[2]: SBLS KKT saddle point of a synthetic QP, n = 1e6, m = 2e5, through the
+    real SBLS; three form_and_factorize + solve rounds (new values, same structure) as CQP would do."""
+    refio = _need()
+    n, m = 1000000, 200000
+    H, A, C = _qp_kkt(n, m, 20240102)
+    x, y = np.ones(n), np.ones(m)
+    rhs = _kkt_rhs(n, m, H, A, x, y)
+    r = refio.run_sbls(n, m, H, A, C, rhs, solver="gsls", factorization=2, repeat=3, timeout=1500)
+    assert (r["status_factorize"], r["status_solve"]) == (0, 0)
+    assert r["negative_eigenvalues"] == m
+    assert np.abs(r["sol"] - 1.0).max() <= 1e-7
+    print("cfg3 through SBLS: factorize median %.3f s, solve median %.3f s" % (
+        r["t_factorize_median"], r["t_solve_median"]))
