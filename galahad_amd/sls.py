@@ -35,18 +35,21 @@ GALAHAD_error_technical = -50
 
 
 def _status_from_flag(flag):
-    """SLS_copy_inform_from_ssids, src/sls/sls.f90:1747-1780"""
+    """SLS_copy_inform_from_gsls (integration/patch_sls.py) = SLS_copy_inform_from_ssids,
+    src/sls/sls.f90:1747-1780, except that -6 'not positive definite' maps to GALAHAD_error_inertia
+    like the MA57/MA97/SYTR arms do (TRS steers on that code, src/trs/trs.f90:1957, 2287); the ssids
+    arm's -6 -> GALAHAD_error_restrictions makes TRS unusable with it."""
     if flag >= 0:
         return GALAHAD_ok
     if flag == -30:
         return GALAHAD_error_allocate
     if flag == -31:
         return GALAHAD_error_deallocate
-    if flag in (-1, -2, -3, -4, -5, -6, -9, -10, -12, -13, -14, -15):
+    if flag in (-1, -2, -3, -4, -5, -9, -10, -12, -13, -14, -15):
         return GALAHAD_error_restrictions
     if flag == -11:
         return GALAHAD_error_permutation
-    if flag in (-7, -8):
+    if flag in (-6, -7, -8):
         return GALAHAD_error_inertia
     if flag in (-32, GALAHAD_unavailable_option):
         return GALAHAD_unavailable_option

@@ -172,8 +172,11 @@ COPY_ROUTINES = """
 
      SUBROUTINE SLS_copy_inform_from_gsls( inform, info_gsls )
 
-!  copy inform parameters from their GSLS equivalents (cf. SLS_copy_inform_from_ssids:
-!  the flag space is that of SSIDS, so the status mapping is the same)
+!  copy inform parameters from their GSLS equivalents (cf. SLS_copy_inform_from_ssids: the flag
+!  space is that of SSIDS and the mapping is the same, with ONE deliberate difference: "not positive
+!  definite" (-6) becomes GALAHAD_error_inertia, as for MA57/MA97/SYTR, not GALAHAD_error_restrictions
+!  as in the ssids arm -- TRS/RQS steer their secular iteration on exactly that code
+!  (src/trs/trs.f90:1957, 2287) and cannot work with the ssids arm's mapping)
 
      TYPE ( SLS_inform_type ), INTENT( INOUT ) :: inform
      TYPE ( gsls_inform ), INTENT( IN ) :: info_gsls
@@ -194,11 +197,11 @@ COPY_ROUTINES = """
        inform%status = GALAHAD_error_allocate
      CASE ( - 31  )
        inform%status = GALAHAD_error_deallocate
-     CASE( - 1, - 2, - 3, - 4, - 5, - 6, - 9, - 10, - 12, - 13, - 14, - 15 )
+     CASE( - 1, - 2, - 3, - 4, - 5, - 9, - 10, - 12, - 13, - 14, - 15 )
        inform%status = GALAHAD_error_restrictions
      CASE ( - 11 )
        inform%status = GALAHAD_error_permutation
-     CASE ( - 7, - 8  )
+     CASE ( - 6, - 7, - 8  )
        inform%status = GALAHAD_error_inertia
      CASE ( - 32, GALAHAD_unavailable_option  )
        inform%status = GALAHAD_unavailable_option

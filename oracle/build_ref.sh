@@ -94,9 +94,10 @@ fc dum/mkl_pardiso.f90
 fc dum/pardiso.f90
 fc dum/wsmp.f90
 fc sls/sls.f90
-# SBLS (saddle-point / KKT layer above SLS) and what it USEs; ULS/GLS only for its implicit variants
+# SBLS (saddle-point / KKT layer above SLS) and TRS (trust-region subproblem) and what they USE;
+# ULS/GLS only for SBLS's implicit variants
 for f in lmt/lmt.f90 qpt/qpt.f90 roots/roots.f90 norms/norms.f90 gls/gls.f90 dum/hsl_ma48d.f90 \
-         uls/uls.f90 sbls/sbls.f90 ; do fc $f ; done
+         uls/uls.f90 sbls/sbls.f90 rand/rand.f90 ir/ir.f90 mop/mop.f90 trs/trs.f90 ; do fc $f ; done
 for f in dum/ma33d.f dum/mc13d.f dum/mc21d.f dum/mc22d.f dum/mc23d.f dum/mc29d.f \
          dum/mc30d.f ; do ff $f ; done
 wait $p1 $p2 $p3
@@ -105,6 +106,7 @@ wait $p1 $p2 $p3
 $FC -fopenmp -shared -o $OUT/libgalahad_ref.so $W/obj/*.o -lstdc++
 $FC $FFLAGS -o $OUT/ref_driver $HERE/ref_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
 $FC $FFLAGS -o $OUT/sbls_driver $HERE/sbls_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
+$FC $FFLAGS -o $OUT/trs_driver $HERE/trs_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
 echo "build_ref: wrote $OUT/libgalahad_ref.so and $OUT/ref_driver"
 
 # ---- drop-in build: the REAL SLS facade with the gsls arms of INTEGRATION.md, linked to the MI355X
@@ -124,5 +126,11 @@ if [ -f "$GSLS_LIB" ]; then
   $FC $F2 -o $OUT/sbls_gsls_driver $HERE/sbls_driver.f90 $W/obj2_sbls.o \
       $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
       -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
-  echo "build_ref: wrote $OUT/sls_gsls_driver, $OUT/sbls_gsls_driver (GALAHAD SLS/SBLS + gsls backend)"
+  # TRS (and the IR it calls) above the patched SLS
+  $FC $F2 -c -o $W/obj2_ir.o $S/ir/ir.f90
+  $FC $F2 -c -o $W/obj2_trs.o $S/trs/trs.f90
+  $FC $F2 -o $OUT/trs_gsls_driver $HERE/trs_driver.f90 $W/obj2_trs.o $W/obj2_ir.o \
+      $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  echo "build_ref: wrote $OUT/sls_gsls_driver, sbls_gsls_driver, trs_gsls_driver (GALAHAD SLS/SBLS/TRS + gsls backend)"
 fi

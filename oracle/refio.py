@@ -161,3 +161,43 @@ def run_sbls(n, m, H, A, Cm, rhs, *, solver="gsls", factorization=2, repeat=1, i
                     rank=int(ints[3]), negative_eigenvalues=int(ints[4]), t_factorize=float(tms[0]),
                     t_solve=float(tms[1]), t_factorize_median=float(tms[2]), t_solve_median=float(tms[3]),
                     sol=sol)
+
+
+TRS_DRIVER = os.path.join(HERE, "_ref", "trs_driver")
+TRS_DROPIN = os.path.join(HERE, "_ref", "trs_gsls_driver")
+
+
+def trs_available(dropin=False):
+    p = TRS_DROPIN if dropin else TRS_DRIVER
+    return os.path.exists(p) and os.access(p, os.X_OK)
+
+
+def run_trs(n, H, c, radius, f=0.0, *, solver="gsls", mdiag=0.0, print_level=0, timeout=3600):
+    """TRS_solve: min 1/2 x'Hx + c'x + f s.t. ||x||_M <= radius.  H = (row, col, val) lower, 1-based."""
+    exe = TRS_DROPIN if solver == "gsls" else TRS_DRIVER
+    if not os.path.exists(exe):
+        raise RuntimeError("%s not built" % exe)
+    with tempfile.TemporaryDirectory(prefix="gsls_trs_") as d:
+        pin, pout = os.path.join(d, "p.bin"), os.path.join(d, "r.bin")
+        with open(pin, "wb") as fh:
+            fh.write(struct.pack("<2i", 1414681344, 1))
+            fh.write(struct.pack("<4i", n, len(H[0]), SOLVERS[solver], print_level))
+            fh.write(struct.pack("<3d", radius, f, mdiag))
+            fh.write(np.ascontiguousarray(H[0], dtype=np.int32).tobytes())
+            fh.write(np.ascontiguousarray(H[1], dtype=np.int32).tobytes())
+            fh.write(np.ascontiguousarray(H[2], dtype=np.float64).tobytes())
+            fh.write(np.ascontiguousarray(c, dtype=np.float64).tobytes())
+        env = dict(os.environ)
+        env["OMP_CANCELLATION"] = "true"
+        cmd = "ulimit -s unlimited 2>/dev/null; exec '%s' '%s' '%s'" % (exe, pin, pout)
+        p = subprocess.run(["bash", "-c", cmd], env=env, capture_output=True, text=True, timeout=timeout)
+        if p.returncode != 0 or not os.path.exists(pout):
+            raise RuntimeError("trs driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
+        if print_level:
+            print(p.stdout)
+        buf = open(pout, "rb").read()
+        ints = np.frombuffer(buf, dtype="<i4", count=4)
+        dbl = np.frombuffer(buf, dtype="<f8", count=4, offset=16)
+        x = np.frombuffer(buf, dtype="<f8", count=n, offset=48).copy()
+        return dict(status=int(ints[0]), factorizations=int(ints[1]), obj=float(dbl[0]),
+                    multiplier=float(dbl[1]), x_norm=float(dbl[2]), time=float(dbl[3]), x=x)

@@ -155,7 +155,8 @@ def test_not_positive_definite_and_singular_status():
     from galahad_amd import sls as S
     s, m, c, i = run_gsls(P.kat_indefinite(), True)
     assert i.gsls_inform["flag"] == -6             # SSIDS_ERROR_NOT_POS_DEF
-    assert i.status == S.GALAHAD_error_restrictions   # the quirk of sls.f90:1768 (-6 -> -3)
+    assert i.status == S.GALAHAD_error_inertia     # what TRS expects (trs.f90:1957); the ssids arm's
+    #                                                quirk (-6 -> -3, sls.f90:1768) is NOT copied
     s.terminate()
     n = 6
     idx = np.arange(1, n + 1, dtype=np.int32)
@@ -260,7 +261,7 @@ def test_cfg4_grid_indefinite_and_shifted_posdef():
     assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-13
     s.terminate()
     s, m, c, i = run_gsls(prob, True, ordering_free=True)            # H - I is not PD
-    assert i.gsls_inform["flag"] == -6 and i.status == S.GALAHAD_error_restrictions
+    assert i.gsls_inform["flag"] == -6 and i.status == S.GALAHAD_error_inertia
     s.terminate()
     prob = P.grid2d(707, 707, shift=-0.5)                             # H + 0.5 I
     s, m, c, i = run_gsls(prob, True, ordering_free=True)

@@ -56,7 +56,7 @@ def test_dropin_matches_reference_golden(path):
 @pytest.mark.gpu
 def test_dropin_defaults_refinement_and_not_posdef():
     """solver-specific defaults (own ordering, no PERM), SLS's own iterative refinement loop
-    (sls.f90:4751-4963) around the backend, and the -6 -> GALAHAD_error_restrictions quirk."""
+    (sls.f90:4751-4963) around the backend, and 'not positive definite' -> GALAHAD_error_inertia."""
     refio = _need_dropin()
     prob = P.kkt_qpband(20000, 4000)
     n, row, col, val, rhs, xs = prob
@@ -66,4 +66,4 @@ def test_dropin_defaults_refinement_and_not_posdef():
     assert P.scaled_residual(n, row, col, val, r["x"], rhs) <= 1e-14
     n, row, col, val, rhs, xs = P.kat_indefinite()
     r = refio.run(n, row, col, val, rhs, solver="gsls", pivot_control=2)
-    assert r["status_factorize"] == -3
+    assert r["status_factorize"] == -20
