@@ -136,15 +136,30 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
     int jsep = -1;
     if (!leaf) {
       // narrowest level whose two sides both keep at least 30 % of the vertices
-      int64_t best_w = -1;
+      // Candidates: levels that leave at least 30 % of the vertices on either side.  Among those within
+      // 15 % of the narrowest one, take the cut that minimises the DEPTH of the dissection tree it
+      // leads to (a side spanning k levels of the structure needs about ceil(log2(k+1)) further
+      // cuts), then the better balance.  Every tree level is a chain of dependent launches on the
+      // GPU, so depth is worth more than the last few per cent of fill.
+      int wmin = -1;
       for (int j = 1; j + 1 < nl; ++j) {
         const int left = lptr[j], right = cnt - lptr[j + 1], wj = lptr[j + 1] - lptr[j];
         if (left < 0.3 * cnt || right < 0.3 * cnt) continue;
-        const int64_t imbalance = std::abs(left - right);
-        const int64_t score = int64_t(wj) * 16 + imbalance * 16 / cnt;
-        if (best_w < 0 || score < best_w) {
-          best_w = score;
+        if (wmin < 0 || wj < wmin) wmin = wj;
+      }
+      auto depth_of = [](int k) { int d = 0; while ((1 << d) - 1 < k) ++d; return d; };
+      int best_depth = -1;
+      int64_t best_imb = 0;
+      for (int j = 1; j + 1 < nl && wmin >= 0; ++j) {
+        const int left = lptr[j], right = cnt - lptr[j + 1], wj = lptr[j + 1] - lptr[j];
+        if (left < 0.3 * cnt || right < 0.3 * cnt) continue;
+        if (wj > wmin + wmin * 0.15) continue;
+        const int dep = std::max(depth_of(j), depth_of(nl - j - 1));
+        const int64_t imb = std::abs(left - right);
+        if (jsep < 0 || dep < best_depth || (dep == best_depth && imb < best_imb)) {
           jsep = j;
+          best_depth = dep;
+          best_imb = imb;
         }
       }
       if (jsep < 0) {   // no balanced cut: take the level holding the median vertex

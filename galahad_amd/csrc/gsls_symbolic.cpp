@@ -153,8 +153,15 @@ struct Supernodes {
   std::vector<int> sptr, sparent, scc;
 };
 
+// keep_branches (our own orderings only -- with a user PERM the reference's partition is reproduced
+// exactly): do not let the "no extra fill" rule merge a column into a parent that is a BRANCHING
+// point of the elimination tree (two or more sizeable child subtrees).  The merged supernode would
+// eliminate the child's columns and the parent's as one block, so the other subtrees -- which only
+// feed the parent's own columns -- could no longer overlap with the child's: for nested dissection
+// that doubles the number of dependent pivots on the critical path (child separator + parent
+// separator at every level instead of one).
 void relaxed_supernodes(int n, int realn, const std::vector<int>& parent,
-                        const std::vector<int>& cc, int nemin, Supernodes& out) {
+                        const std::vector<int>& cc, int nemin, bool keep_branches, Supernodes& out) {
   const int64_t kNever = INT64_MAX;
   std::vector<int> nelim(n + 1, 1), nvert(n + 1, 1), mhead(n + 1, -1), mnext(n + 1, -1);
   std::vector<int64_t> ezero(n + 1, 0);
@@ -167,15 +174,22 @@ void relaxed_supernodes(int n, int realn, const std::vector<int>& parent,
     next[i] = head[parent[i]];
     head[parent[i]] = i;
   }
+  std::vector<int> subtree(n + 1, 1);   // vertices in the elimination subtree of each column
+  if (keep_branches)
+    for (int i = 0; i < realn; ++i) subtree[parent[i]] += subtree[i];
   std::vector<int> kids;
   for (int par = 0; par <= n; ++par) {
     kids.clear();
     for (int c = head[par]; c != -1; c = next[c]) kids.push_back(c);
     std::stable_sort(kids.begin(), kids.end(), [&](int a, int b) { return cc[a] > cc[b]; });
+    int big_kids = 0;
+    if (keep_branches)
+      for (int c : kids) big_kids += (subtree[c] >= 2 * nemin);
     for (int c : kids) {
       bool merge = false;
       if (ezero[par] != kNever)
-        merge = (cc[par] == cc[c] - 1 && nelim[par] == 1) || (nelim[par] < nemin && nelim[c] < nemin);
+        merge = (cc[par] == cc[c] - 1 && nelim[par] == 1 && big_kids < 2) ||
+                (nelim[par] < nemin && nelim[c] < nemin);
       if (merge) {
         mnext[c] = mhead[par];
         mhead[par] = c;
@@ -259,7 +273,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
   if (S.realn != n) flag = GSLS_WARNING_ANAL_SINGULAR;
   column_counts(n, aptr, arow, S.perm, S.invp, parent, cc);
   Supernodes sn;
-  relaxed_supernodes(n, S.realn, parent, cc, nemin, sn);
+  relaxed_supernodes(n, S.realn, parent, cc, nemin, ordering != GSLS_ORDER_USER, sn);
 
   // final pivot order = supernode renumbering applied on top of the postorder
   {
