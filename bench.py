@@ -47,6 +47,11 @@ def parse():
                     help="free: the backend's own ordering (perf run); natural: identity PERM (parity run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nemin", type=int, default=0, help="supernode amalgamation (0: backend default)")
+    ap.add_argument("--shard", choices=["replicas", "tree"], default="replicas",
+                    help="N>1: replicas = one independent system per GPU (weak scaling, the default); tree = "
+                         "ONE system, elimination-tree subtrees dealt to the GPUs (strong scaling)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     return ap.parse_args()
 
 
@@ -96,14 +101,18 @@ def main():
     from galahad_amd import dist as gdist
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import problems as P
     from galahad_amd import SLS, SMT, Control, InformSLS
     from galahad_amd._lib import Inform, lib
 
     # every rank owns one independent system of the same shape (different seed): weak scaling
-    prob = P.banded_spd(a.n, a.semibw, seed=20240101 + rank)
+    tree = a.shard == "tree" and world > 1
+    prob = P.banded_spd(a.n, a.semibw, seed=20240101 + (0 if tree else rank))
     n, row, col, val, rhs, xs = prob
     m = SMT(n, "COORDINATE", row=row, col=col, val=val)
     s, c, inf = SLS(), Control(), InformSLS()
@@ -126,7 +135,18 @@ def main():
     d_x = torch.empty_like(d_rhs)
     ginf = Inform()
 
+    ts = None
+    if tree:
+        from galahad_amd.shard import TreeShardedSLS
+        ts = TreeShardedSLS(s)
+
     def step():
+        if ts is not None:
+            st = ts.factorize_dev(d_val, True)
+            assert st["flag"] == 0, st
+            d_x.copy_(d_rhs)
+            ts.solve_dev(d_x)
+            return
         f = lib.gsls_factor_dev(s.handle, 1, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts), C.byref(ginf))
         assert f == 0, f
         d_x.copy_(d_rhs)
@@ -166,10 +186,13 @@ def main():
             s2.analyse(m, c2, i2, PERM=np.arange(1, n + 1))
             F = i2.flops_elimination
             s2.terminate()
-        value = world * a.steps * F / elapsed / 1e9
+        value = (1 if tree else world) * a.steps * F / elapsed / 1e9
         solve_bytes = 2 * 8 * nnzL + 4 * 8 * n
         t_sweep = float(np.mean(ksolve))
-        achieved = solve_bytes / t_sweep / 1e9
+        if tree or t_sweep <= 0:   # the sharded solve is four phases with collectives between: no single sweep
+            t_sweep, achieved = None, None
+        else:
+            achieved = solve_bytes / t_sweep / 1e9
         # HBM bytes of one solve sweep from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected separately with rocprofv3 --pmc and committed; only valid for the profiled config
         traffic = None
@@ -180,17 +203,18 @@ def main():
         out = {
             "metric": "SLS factorize+solve GF/s (fp64)", "value": value, "unit": "GF/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if tree else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SLS standalone: random banded SPD n=%d, semi-bandwidth=%d, fp64 "
-                                   "(BASELINE.json configs[1]); one system per GPU" % (a.n, a.semibw),
+                                   "(BASELINE.json configs[1]); %s" % (a.n, a.semibw, "one system, tree-sharded over the GPUs" if tree
+                                                                      else "one system per GPU"),
                        "ordering": a.ordering, "node_amalgamation": c.node_amalgamation, "flops_numerator": F,
                        "flops_executed_per_step": flops_used, "entries_in_factors": nnzL,
                        "levels": inf.gsls_inform["nlevels"], "supernodes": inf.gsls_inform["num_sup"],
                        "analyse_s": t_analyse, "scaled_residual": res},
             "roofline": {"bound": "hbm", "kernel": "triangular solve sweep (fwd+diag+bwd kernels)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": None if achieved is None else achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": solve_bytes, "seconds_per_launch": t_sweep},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -54,6 +54,13 @@ SIGNATURES = {
     "gsls_alter": (C.c_int, [C.c_void_p, p_f64, C.POINTER(Inform)]),
     "gsls_get_symbolic_sizes": (C.c_int, [C.c_void_p, p_i32, p_i64, p_i64]),
     "gsls_get_symbolic": (C.c_int, [C.c_void_p, p_i32, p_i32, p_i64, p_i32, p_i64, p_i64]),
+    "gsls_shard": (C.c_int, [C.c_void_p, i32, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gsls_shard_factor_dev": (C.c_int, [C.c_void_p, i32, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),
+                                        C.POINTER(Inform)]),
+    "gsls_shard_solve_dev": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
+    "gsls_shard_failed": (C.c_int, [C.c_void_p, C.POINTER(i32), p_i32]),
+    "gsls_shard_repair": (C.c_int, [C.c_void_p, i32, p_i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gsls_shard_get": (C.c_int, [C.c_void_p, p_i32, C.POINTER(i32), p_i32]),
     "gsls_get_stream": (C.c_void_p, [C.c_void_p]),
     "gsls_last_solve_kernel_seconds": (C.c_int, [C.c_void_p, p_f64, p_f64, p_f64]),
     "gsls_device_count": (C.c_int, []),

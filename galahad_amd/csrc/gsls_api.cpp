@@ -439,6 +439,184 @@ int gsls_solve_dev(void* handle, int32_t job, int32_t nrhs, double* d_x, int32_t
   return solve_common(static_cast<Handle*>(handle), job, nrhs, d_x, ldx, true, inform);
 }
 
+// ---- multi-GPU: elimination-tree sharding (anal.f90:284-459, 569-590) -------------
+// Every rank analyses the same matrix, then calls gsls_shard(nranks, rank).  The two exchange steps are
+// the caller's (torch.distributed / RCCL): see galahad_amd/shard.py.
+int gsls_shard(void* handle, int32_t nranks, int32_t rank, int64_t* xchg_factor_elems,
+               int64_t* xchg_solve_elems) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return GSLS_ERROR_CALL_SEQUENCE;
+  shard_tree(h->S, nranks);
+  h->F.myrank = rank;
+  h->dev_ready = false;   // plans are rebuilt on the next factorization
+  h->factored = false;
+  int64_t ce = 0, ve = 0;
+  for (int c : h->S.cutroots) {
+    const int64_t cm = h->S.nrow(c) - h->S.ncol(c);
+    ce += cm * cm;
+    ve += cm;
+  }
+  if (xchg_factor_elems) *xchg_factor_elems = std::max<int64_t>(ce, 1);
+  if (xchg_solve_elems) *xchg_solve_elems = std::max<int64_t>(std::max<int64_t>(ve, h->S.n), 1);
+  return GSLS_SUCCESS;
+}
+
+// phase 1: factorize the subtrees this rank owns, pack the cut roots' contribution blocks into
+// d_xchg (zeros for the other ranks' roots); the caller then SUMs d_xchg over ranks (at least onto
+// rank 0).  phase 2: rank 0 factorizes the top part (no-op elsewhere).  inform holds THIS rank's
+// counts (num_neg, num_two, matrix_rank deficiency); the caller adds them up.
+int gsls_shard_factor_dev(void* handle, int32_t phase, int32_t posdef, const double* d_val, double* d_xchg,
+                          const gsls_options* options, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || h->S.nranks < 2 || h->S.owner.empty()) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  inform->hip_error = 0;
+  gsls_options defo;
+  if (!options) {
+    gsls_default_options(&defo);
+    options = &defo;
+  }
+  const Symbolic& S = h->S;
+  if (phase == 1) h->factored = false;
+  if (S.n == 0) {
+    h->factored = true;
+    h->posdef = posdef != 0;
+    return GSLS_SUCCESS;
+  }
+  if (!d_val || !d_xchg) return inform->flag = GSLS_ERROR_VAL;
+  const double t0 = now();
+  hipError_t e = ensure_device(h, options);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  DeviceGuard g(h->device);
+  if (!h->dev_ready) {
+    e = dev_upload_symbolic(S, h->F, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    h->dev_ready = true;
+  }
+  h->have_scale = false;
+  e = dev_shard_factor(S, h->F, phase, posdef != 0, d_val, d_xchg, options->small, options->u, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  int32_t st[16];
+  e = hipMemcpyAsync(st, h->F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  h->posdef = posdef != 0;
+  inform->num_neg = inform->num_two = inform->num_delay = 0;
+  inform->matrix_rank = S.n;
+  inform->maxfront = std::max(S.maxfront, S.maxrow);
+  inform->time_factor = now() - t0;
+  if (posdef) {
+    if (st[0] != INT_MAX) return inform->flag = GSLS_ERROR_NOT_POS_DEF;
+  } else {
+    if (st[4] > 0) {   // pivots want to leave their front: the caller gathers every rank's list
+      inform->num_delay = st[4];   // (gsls_shard_failed), repairs the order on all ranks alike
+      return inform->flag;         // (gsls_shard_repair) and starts again at phase 1
+    }
+    inform->num_neg = st[2];
+    inform->num_two = st[3];
+    if (st[1] > 0) {
+      inform->matrix_rank -= st[1];
+      if (!options->action) return inform->flag = GSLS_ERROR_SINGULAR;
+      inform->flag = GSLS_WARNING_FACT_SINGULAR;
+    }
+  }
+  if (phase == 2) {
+    h->factored = true;
+    h->last = *inform;
+  }
+  return inform->flag;
+}
+
+// phases 1-4 of one full solve (job 0) for one right-hand side; d_x (n) holds the right-hand side on
+// every rank before phase 1 and the solution on every rank after phase 4.  Between the phases the
+// caller: SUMs d_xchg[0:V) after 1, BROADCASTs d_xchg[0:n) from rank 0 after 2, SUMs d_xchg[0:n)
+// after 3 (V = total contribution-vector length of the cut roots; d_xchg has xchg_solve_elems).
+int gsls_shard_solve_dev(void* handle, int32_t phase, double* d_x, double* d_xchg, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->factored || h->S.nranks < 2) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  if (h->S.n == 0) return GSLS_SUCCESS;
+  if (!d_x || !d_xchg) return inform->flag = GSLS_ERROR_X_SIZE;
+  DeviceGuard g(h->device);
+  hipError_t e = dev_shard_solve(h->S, h->F, phase, h->posdef, d_x, d_xchg, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  return inform->flag;
+}
+
+// Pivots that failed inside the fronts this rank factorized (pivot positions of the current
+// elimination order, at most GSLS_FAILCAP of them); valid after a factor phase that reported
+// inform.num_delay > 0.
+int gsls_shard_failed(void* handle, int32_t* nfailed, int32_t* failed) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->dev_ready || !nfailed) return GSLS_ERROR_CALL_SEQUENCE;
+  DeviceGuard g(h->device);
+  int32_t st[16];
+  hipError_t e = hipMemcpy(st, h->F.stat, sizeof(st), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return GSLS_ERROR_HIP;
+  const int nf = (st[4] > 0) ? std::min<int>(st[5], FAILCAP) : 0;
+  *nfailed = nf;
+  if (nf > 0 && failed) {
+    e = hipMemcpy(failed, h->F.faillist, nf * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return GSLS_ERROR_HIP;
+  }
+  return GSLS_SUCCESS;
+}
+
+// Apply the elimination-order repair of gsls_factor (failed pivots move to the end of their front or
+// behind their parent's columns) for the union of all ranks' failed pivots, re-analyse and re-shard.
+// Every rank must pass the same list; the result is identical on every rank.
+int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed_in, int64_t* xchg_factor_elems,
+                      int64_t* xchg_solve_elems) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || h->S.nranks < 2 || nfailed < 0 || (nfailed > 0 && !failed_in))
+    return GSLS_ERROR_CALL_SEQUENCE;
+  std::vector<int32_t> failed(failed_in, failed_in + nfailed), order;
+  std::sort(failed.begin(), failed.end());
+  failed.erase(std::unique(failed.begin(), failed.end()), failed.end());
+  if (!repair_order(h->S, failed, order)) return GSLS_ERROR_UNIMPLEMENTED;
+  const int nranks = h->S.nranks, rank = h->F.myrank;
+  int flag;
+  try {
+    flag = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin,
+                            h->S);
+  } catch (const std::bad_alloc&) {
+    return GSLS_ERROR_ALLOCATION;
+  }
+  if (flag < 0) return flag;
+  fill_from_symbolic(h->S, &h->last);
+  h->last.factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+  return gsls_shard(handle, nranks, rank, xchg_factor_elems, xchg_solve_elems);
+}
+
+// owner rank of every supernode (-1: top part) and the cut roots, for callers that want to inspect
+// the partition; either pointer may be NULL
+int gsls_shard_get(void* handle, int32_t* owner, int32_t* ncut, int32_t* cutroots) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
+  if (owner)
+    for (size_t i = 0; i < h->S.owner.size(); ++i) owner[i] = h->S.owner[i];
+  if (ncut) *ncut = int32_t(h->S.cutroots.size());
+  if (cutroots)
+    for (size_t i = 0; i < h->S.cutroots.size(); ++i) cutroots[i] = h->S.cutroots[i] + 1;
+  return GSLS_SUCCESS;
+}
+
 // d[i] = diagonal of the Cholesky factor in pivot order (NumericSubtree.hxx:418-427)
 int gsls_enquire_posdef(void* handle, double* d, gsls_inform* inform) {
   gsls_inform local;

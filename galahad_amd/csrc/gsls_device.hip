@@ -1281,6 +1281,52 @@ k_big_bwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ t
   }
 }
 
+// =================================================================================================
+// multi-GPU exchange helpers: pack / unpack the cut roots' blocks, merge / mask solution vectors
+// =================================================================================================
+struct Segment {
+  int64_t src, dst, len;   // element offsets in the arena and in the exchange buffer
+  int32_t owner, pad;
+};
+// dir 0: buf[dst..] = (owner == me ? arena[src..] : 0) ; dir 1: arena[src..] = buf[dst..]
+__global__ void k_segments(const Segment* __restrict__ seg, double* __restrict__ arena,
+                           double* __restrict__ buf, int dir, int me) {
+  const Segment sg = seg[blockIdx.y];
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < sg.len;
+       i += int64_t(gridDim.x) * blockDim.x) {
+    if (dir == 0) buf[sg.dst + i] = (sg.owner == me) ? arena[sg.src + i] : 0.0;
+    else arena[sg.src + i] = buf[sg.dst + i];
+  }
+}
+// mode 0: xp[i] = xq[i] where the position belongs to the top part
+// mode 1: xp[i] = 0 where this rank did not compute position i (top counts for rank 0)
+__global__ void k_xmask(int n, const int32_t* __restrict__ posowner, double* __restrict__ xp,
+                        const double* __restrict__ xq, int mode, int me) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = posowner[i];
+  if (mode == 0) { if (o < 0) xp[i] = xq[i]; }
+  else if (!(o == me || (o < 0 && me == 0))) xp[i] = 0.0;
+}
+// D solve restricted to the positions of one owner class (sel = rank, or -1 for the top part)
+__global__ void k_solve_diag_owned(int n, const double* __restrict__ D, const int32_t* __restrict__ gperm,
+                                   const int32_t* __restrict__ posowner, int sel, double* __restrict__ xp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || posowner[i] != sel) return;
+  const double d0 = D[2 * int64_t(i)];
+  if (isinf(d0)) return;
+  const int gi = gperm[i];
+  if (i + 1 < n && isinf(D[2 * int64_t(i) + 2])) {
+    const int gj = gperm[i + 1];
+    const double d21 = D[2 * int64_t(i) + 1], d22 = D[2 * int64_t(i) + 3];
+    const double x1 = xp[gi], x2 = xp[gj];
+    xp[gi] = d0 * x1 + d21 * x2;
+    xp[gj] = d21 * x1 + d22 * x2;
+  } else {
+    xp[gi] *= d0;
+  }
+}
+
 __global__ void k_iota(int n, int32_t* __restrict__ a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = i;
@@ -1307,7 +1353,7 @@ void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.asmtasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part};
+                  F.biggemv, F.ybuf, F.part, F.segC, F.segV, F.posowner};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -1327,7 +1373,9 @@ static hipError_t allow_big_lds() {
 }
 
 hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st) {
+  const int me = F.myrank;
   dev_free(F);
+  F.myrank = me;
   HIPCHK(allow_big_lds());
   const int nn = S.nnodes;
   std::vector<NodeDesc> nd(nn);
@@ -1370,27 +1418,33 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<BigTrsv> btr;
   std::vector<BigGemv> bgm;
   int64_t part_max = 0;
-  F.plan.assign(S.nlevels, LevelPlan());
+  // one plan per node subset: everything (single device), my subtrees, the top part (multi-GPU)
+  auto build_plan = [&](std::vector<LevelPlan>& plan, auto keep) {
+  plan.assign(S.nlevels, LevelPlan());
+  std::vector<int> lvl_nodes;
   for (int l = 0; l < S.nlevels; ++l) {
-    LevelPlan& lp = F.plan[l];
-    lp.node_begin = S.lvlptr[l];
-    lp.node_end = S.lvlptr[l + 1];
+    LevelPlan& lp = plan[l];
+    lvl_nodes.clear();
+    for (int i = S.lvlptr[l]; i < S.lvlptr[l + 1]; ++i)
+      if (keep(S.lvlnodes[i])) lvl_nodes.push_back(S.lvlnodes[i]);
+    lp.node_begin = 0;
+    lp.node_end = int(lvl_nodes.size());
     int maxsteps = 0;
     for (int i = lp.node_begin; i < lp.node_end; ++i)
-      maxsteps = std::max(maxsteps, (S.ncol(S.lvlnodes[i]) + NB - 1) / NB);
+      maxsteps = std::max(maxsteps, (S.ncol(lvl_nodes[i]) + NB - 1) / NB);
     // per step: diag tasks first, then the extra row chunks
     lp.panel_begin.assign(2 * maxsteps, 0);
     lp.panel_cnt.assign(2 * maxsteps, 0);
     for (int st_ = 0; st_ < maxsteps; ++st_) {
       lp.panel_begin[2 * st_] = int(pt.size());
       for (int i = lp.node_begin; i < lp.node_end; ++i) {
-        const int s = S.lvlnodes[i];
+        const int s = lvl_nodes[i];
         if (S.ncol(s) > st_ * NB) pt.push_back(PanelTask{s, st_, 0, 0});
       }
       lp.panel_cnt[2 * st_] = int(pt.size()) - lp.panel_begin[2 * st_];
       lp.panel_begin[2 * st_ + 1] = int(pt.size());
       for (int i = lp.node_begin; i < lp.node_end; ++i) {
-        const int s = S.lvlnodes[i];
+        const int s = lvl_nodes[i];
         if (S.ncol(s) <= st_ * NB) continue;
         const int rem = S.nrow(s) - st_ * NB - PR;
         for (int c = 1; (c - 1) * RB < rem; ++c) pt.push_back(PanelTask{s, st_, c, 0});
@@ -1399,7 +1453,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     }
     lp.tile_begin = int(tt.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
-      const int s = S.lvlnodes[i];
+      const int s = lvl_nodes[i];
       if (S.sparent[s] >= nn) continue;  // roots have no (used) contribution block
       const int cm = S.nrow(s) - S.ncol(s);
       const int nt = (cm + TS - 1) / TS;
@@ -1411,7 +1465,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     for (int rk = 0; rk < ASM_RANKS; ++rk) {
       lp.asmt_begin[rk] = int(at.size());
       for (int i = lp.node_begin; i < lp.node_end; ++i) {
-        const int s = S.lvlnodes[i];
+        const int s = lvl_nodes[i];
         if (S.cptr[s] + rk >= S.cptr[s + 1]) continue;
         const int c = S.clist[S.cptr[s] + rk];
         const int cm = S.nrow(c) - S.ncol(c);
@@ -1421,7 +1475,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     }
     lp.asm_begin = int(asmn.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
-      const int s = S.lvlnodes[i];
+      const int s = lvl_nodes[i];
       if (S.cptr[s + 1] - S.cptr[s] > ASM_RANKS) asmn.push_back(s);
     }
     lp.asm_cnt = int(asmn.size()) - lp.asm_begin;
@@ -1431,7 +1485,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     lp.small_maxn = lp.small_maxm = 0;
     int big_maxn = 0;
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
-      const int s = S.lvlnodes[i];
+      const int s = lvl_nodes[i];
       if (S.ncol(s) > BIG_N || S.nrow(s) > BIG_M) {
         bign.push_back(s);
         big_maxn = std::max(big_maxn, S.ncol(s));
@@ -1465,6 +1519,13 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       lp.bigsteps.push_back(bs);
     }
   }
+  };
+  build_plan(F.plan, [](int) { return true; });
+  F.sharded = !S.owner.empty() && S.nranks > 1;
+  if (F.sharded) {
+    build_plan(F.planA, [&](int s) { return S.owner[s] == F.myrank; });
+    build_plan(F.planB, [&](int s) { return S.owner[s] < 0; });
+  }
 
   HIPCHK(upload(F.nodes, nd, st));
   HIPCHK(upload(F.rlist, S.rlist, st));
@@ -1481,6 +1542,29 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     HIPCHK(upload(d2, bgm, st));
     F.bigtrsv = d1;
     F.biggemv = d2;
+  }
+  if (F.sharded) {
+    std::vector<Segment> sc, sv;
+    int64_t oc = 0, ov = 0;
+    for (int c : S.cutroots) {
+      const int64_t cm = S.nrow(c) - S.ncol(c);
+      sc.push_back(Segment{S.coff[c], oc, cm * cm, S.owner[c], 0});
+      sv.push_back(Segment{S.cmapptr[c], ov, cm, S.owner[c], 0});
+      oc += cm * cm;
+      ov += cm;
+    }
+    F.nseg = int(sc.size());
+    F.xchgC_elems = oc;
+    F.xchgV_elems = ov;
+    Segment *d1 = nullptr, *d2 = nullptr;
+    HIPCHK(upload(d1, sc, st));
+    HIPCHK(upload(d2, sv, st));
+    F.segC = d1;
+    F.segV = d2;
+    std::vector<int32_t> po(S.n, -1);
+    for (int s = 0; s < nn; ++s)
+      for (int p2 = S.sptr[s]; p2 < S.sptr[s + 1]; ++p2) po[p2] = S.owner[s];
+    HIPCHK(upload(F.posowner, po, st));
   }
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.ybuf), std::max(S.n, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.part), std::max<int64_t>(part_max, 1) * 64 * sizeof(double)));
@@ -1513,12 +1597,12 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
 
 // -------------------------------------------------------------------------------------------------
 template <bool POSDEF>
-static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, double small, double u,
-                                hipStream_t st) {
+static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::vector<LevelPlan>& plan,
+                                double small, double u, hipStream_t st) {
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
   for (int l = 0; l < S.nlevels; ++l) {
-    const LevelPlan& lp = F.plan[l];
+    const LevelPlan& lp = plan[l];
     for (int rk = 0; rk < ASM_RANKS; ++rk)
       if (lp.asmt_cnt[rk] > 0)
         hipLaunchKernelGGL(k_assemble_tile, dim3(lp.asmt_cnt[rk]), dim3(256), 0, st, F.nodes,
@@ -1560,13 +1644,13 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
     hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, F.nscatter, F.asrc, F.adst, d_val,
                        F.L, d_scale, F.arow, F.acol, F.invp);
   }
-  if (posdef) return factor_levels<true>(S, F, small, u, st);
-  return factor_levels<false>(S, F, small, u, st);
+  if (posdef) return factor_levels<true>(S, F, F.plan, small, u, st);
+  return factor_levels<false>(S, F, F.plan, small, u, st);
 }
 
 template <bool POSDEF>
-static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, double* xp, hipStream_t st,
-                               hipEvent_t* ev) {
+static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::vector<LevelPlan>& plan,
+                               int job, double* xp, hipStream_t st, hipEvent_t* ev, int diag_sel = -2) {
   const bool do_fwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
   const bool do_diag = !POSDEF && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_DIAG ||
                                    job == GSLS_SOLVE_JOB_DIAG_BWD);
@@ -1577,7 +1661,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
   if (ev) HIPCHK(hipEventRecord(ev[0], st));
   if (do_fwd)
     for (int l = 0; l < S.nlevels; ++l) {
-      const LevelPlan& lp = F.plan[l];
+      const LevelPlan& lp = plan[l];
       if (lp.small_cnt > 0)
         hipLaunchKernelGGL(k_solve_fwd<POSDEF>, dim3(lp.small_cnt), dim3(256),
                            sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
@@ -1597,12 +1681,17 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, int job, doub
       }
     }
   if (ev) HIPCHK(hipEventRecord(ev[1], st));
-  if (do_diag)
-    hipLaunchKernelGGL(k_solve_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm, xp);
+  if (do_diag) {
+    if (diag_sel == -2)
+      hipLaunchKernelGGL(k_solve_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm, xp);
+    else
+      hipLaunchKernelGGL(k_solve_diag_owned, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm,
+                         F.posowner, diag_sel, xp);
+  }
   if (ev) HIPCHK(hipEventRecord(ev[2], st));
   if (do_bwd)
     for (int l = S.nlevels - 1; l >= 0; --l) {
-      const LevelPlan& lp = F.plan[l];
+      const LevelPlan& lp = plan[l];
       if (lp.big_cnt > 0) {
         hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
                            F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 1);
@@ -1642,11 +1731,110 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
                                        job == GSLS_SOLVE_JOB_DIAG_BWD);
     hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
                        scale_in ? d_scale : nullptr, F.xp);
-    hipError_t e = posdef ? solve_sweeps<true>(S, F, job, F.xp, st, (r == 0) ? ev : nullptr)
-                          : solve_sweeps<false>(S, F, job, F.xp, st, (r == 0) ? ev : nullptr);
+    hipError_t e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, (r == 0) ? ev : nullptr)
+                          : solve_sweeps<false>(S, F, F.plan, job, F.xp, st, (r == 0) ? ev : nullptr);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.xp,
                        scale_out ? d_scale : nullptr, x);
+  }
+  return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// multi-GPU (elimination-tree sharding).  Every rank holds the whole symbolic structure; rank r
+// factorizes the subtrees it owns, the cut roots' contribution blocks are summed across ranks (each
+// is non-zero on exactly one rank, so the sum is exact and order independent), rank 0 factorizes
+// the top part.
+// -------------------------------------------------------------------------------------------------
+static void launch_segments(const DeviceFactor& F, const void* seg, double* arena, double* buf, int dir,
+                            hipStream_t st) {
+  if (F.nseg > 0)
+    hipLaunchKernelGGL(k_segments, dim3(64, F.nseg), dim3(256), 0, st, static_cast<const Segment*>(seg), arena,
+                       buf, dir, F.myrank);
+}
+
+hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, const double* d_val,
+                            double* d_xchg, double small, double u, hipStream_t st) {
+  if (!F.sharded) return hipErrorInvalidValue;
+  if (phase == 1) {
+    HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
+    const int32_t init[16] = {INT_MAX, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(F.stat, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_iota, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm);
+    if (F.nscatter > 0) {
+      const int blocks = int(std::min<int64_t>((F.nscatter + 255) / 256, 256 * 8));
+      hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, F.nscatter, F.asrc, F.adst, d_val, F.L,
+                         static_cast<const double*>(nullptr), F.arow, F.acol, F.invp);
+    }
+    hipError_t e = posdef ? factor_levels<true>(S, F, F.planA, small, u, st)
+                          : factor_levels<false>(S, F, F.planA, small, u, st);
+    if (e != hipSuccess) return e;
+    launch_segments(F, F.segC, F.C, d_xchg, 0, st);
+  } else if (phase == 2) {
+    if (F.myrank != 0) return hipSuccess;
+    launch_segments(F, F.segC, F.C, d_xchg, 1, st);
+    return posdef ? factor_levels<true>(S, F, F.planB, small, u, st)
+                  : factor_levels<false>(S, F, F.planB, small, u, st);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// phase 1: permute in, forward (+D) over my subtrees, pack the cut roots' contribution vectors
+//          -> caller sums d_xchg[0 : xchgV_elems) over ranks
+// phase 2: rank 0: unpack, forward / D / backward over the top part, d_xchg[0:n) = xp; others: nothing
+//          -> caller broadcasts d_xchg[0:n) from rank 0
+// phase 3: take the top part's solution, backward over my subtrees, d_xchg[0:n) = xp masked to what
+//          this rank computed  -> caller sums d_xchg[0:n) over ranks
+// phase 4: permute out d_xchg[0:n) -> d_x
+hipError_t dev_shard_solve(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, double* d_x,
+                           double* d_xchg, hipStream_t st) {
+  if (!F.sharded) return hipErrorInvalidValue;
+  if (S.n == 0) return hipSuccess;
+  if (F.nrhs_cap < 1) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), std::max(S.n, 1) * sizeof(double)));
+    F.nrhs_cap = 1;
+  }
+  const int blocks = (S.n + 255) / 256;
+  hipError_t e = hipSuccess;
+  switch (phase) {
+    case 1:
+      hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, d_x,
+                         static_cast<const double*>(nullptr), F.xp);
+      e = posdef ? solve_sweeps<true>(S, F, F.planA, GSLS_SOLVE_JOB_FWD, F.xp, st, nullptr)
+                 : solve_sweeps<false>(S, F, F.planA, GSLS_SOLVE_JOB_FWD, F.xp, st, nullptr);
+      if (e != hipSuccess) return e;
+      if (!posdef)
+        hipLaunchKernelGGL(k_solve_diag_owned, dim3(blocks), dim3(256), 0, st, S.n, F.D, F.gperm, F.posowner,
+                           F.myrank, F.xp);
+      launch_segments(F, F.segV, F.cvec, d_xchg, 0, st);
+      break;
+    case 2:
+      if (F.myrank != 0) return hipSuccess;
+      launch_segments(F, F.segV, F.cvec, d_xchg, 1, st);
+      e = posdef ? solve_sweeps<true>(S, F, F.planB, GSLS_SOLVE_JOB_ALL, F.xp, st, nullptr, -1)
+                 : solve_sweeps<false>(S, F, F.planB, GSLS_SOLVE_JOB_ALL, F.xp, st, nullptr, -1);
+      if (e != hipSuccess) return e;
+      HIPCHK(hipMemcpyAsync(d_xchg, F.xp, S.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+      break;
+    case 3:
+      hipLaunchKernelGGL(k_xmask, dim3(blocks), dim3(256), 0, st, S.n, F.posowner, F.xp, d_xchg, 0, F.myrank);
+      e = posdef ? solve_sweeps<true>(S, F, F.planA, GSLS_SOLVE_JOB_BWD, F.xp, st, nullptr)
+                 : solve_sweeps<false>(S, F, F.planA, GSLS_SOLVE_JOB_BWD, F.xp, st, nullptr);
+      if (e != hipSuccess) return e;
+      HIPCHK(hipMemcpyAsync(d_xchg, F.xp, S.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_xmask, dim3(blocks), dim3(256), 0, st, S.n, F.posowner, d_xchg,
+                         static_cast<const double*>(nullptr), 1, F.myrank);
+      break;
+    case 4:
+      hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, d_xchg,
+                         static_cast<const double*>(nullptr), d_x);
+      break;
+    default:
+      return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }

@@ -76,7 +76,18 @@ struct DeviceFactor {
   int32_t* invp = nullptr;     // position -> variable
   int32_t* gperm = nullptr;    // pivot slot -> analyse-time position (numerical pivoting)
   int64_t nscatter = 0;
-  std::vector<LevelPlan> plan;
+  std::vector<LevelPlan> plan;    // every front (single device)
+  std::vector<LevelPlan> planA;   // multi-GPU: the subtrees this rank owns
+  std::vector<LevelPlan> planB;   // multi-GPU: the top part (run by rank 0 after the exchange)
+  bool sharded = false;
+  int myrank = 0;
+  // exchange buffers: contribution blocks / contribution vectors of the cut roots, packed in
+  // S.cutroots order (zeros for roots another rank owns); the buffers themselves belong to the caller
+  int64_t xchgC_elems = 0, xchgV_elems = 0;
+  void* segC = nullptr;           // Segment lists for pack/unpack
+  void* segV = nullptr;
+  int nseg = 0;
+  int32_t* posowner = nullptr;    // pivot position -> owner rank of its front (-1 top)
   // numeric
   double* L = nullptr;
   double* C = nullptr;         // contribution arena
@@ -101,5 +112,10 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
                       const double* d_scale, double small, double u, hipStream_t st);
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);
+// multi-GPU phases (see gsls_shard_factor / gsls_shard_solve in include/gsls.h)
+hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, const double* d_val,
+                            double* d_xchg, double small, double u, hipStream_t st);
+hipError_t dev_shard_solve(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, double* d_x,
+                           double* d_xchg, hipStream_t st);
 
 }  // namespace gsls

@@ -42,6 +42,11 @@ struct Symbolic {
   std::vector<int> ldl;          // leading dimension of each front's L block
   std::vector<int64_t> coff;     // nnodes+1: element offset of each contribution block ((m-n)^2)
 
+  // ---- multi-GPU: subtree ownership (empty = the whole tree on one device) ----------------------
+  int nranks = 1;
+  std::vector<int> owner;        // nnodes: rank that factors the node, -1 = top part (rank 0, after the exchange)
+  std::vector<int> cutroots;     // roots of the distributed subtrees, in exchange-buffer order
+
   int nrow(int node) const { return int(rptr[node + 1] - rptr[node]); }
   int ncol(int node) const { return sptr[node + 1] - sptr[node]; }
 };
@@ -53,6 +58,11 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
 // fill-reducing ordering (nested dissection on the graph of A); writes perm[var] = position (0-based)
 void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow,
                              std::vector<int>& perm);
+
+// Split the assembly tree for `nranks` devices: independent subtrees are dealt to the ranks by decreasing
+// work, everything above them (the top part) stays with rank 0 (cf. find_subtree_partition,
+// src/ssids/anal.f90:284-459).  Fills S.owner / S.cutroots.
+void shard_tree(Symbolic& S, int nranks);
 
 inline int align_ld(int m) { return (m + 1) & ~1; }   // 16-byte aligned columns
 

@@ -450,4 +450,66 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
   return flag;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Subtree partition for multi-GPU runs.  Same idea as the reference's find_subtree_partition
+// (src/ssids/anal.f90:284-459): start from the roots, keep splitting the heaviest subtree at its root
+// until there are enough pieces to balance, deal them out by decreasing flops (longest processing time
+// first); the split-off ancestors form the top part, which one owner (rank 0) factors after it has
+// received the contribution blocks of the cut.
+void shard_tree(Symbolic& S, int nranks) {
+  const int nn = S.nnodes;
+  S.nranks = std::max(1, nranks);
+  S.owner.assign(nn, 0);
+  S.cutroots.clear();
+  if (S.nranks <= 1 || nn == 0) return;
+  std::vector<double> w(nn, 0.0), W(nn, 0.0);
+  for (int s = 0; s < nn; ++s) {
+    const double m = S.nrow(s), ne = S.ncol(s);
+    for (int j = 0; j < int(ne); ++j) w[s] += (m - j) * (m - j);
+    W[s] += w[s];
+    if (S.sparent[s] < nn) W[S.sparent[s]] += W[s];
+  }
+  std::vector<int> cut;
+  std::vector<char> top(nn, 0);
+  for (int s = 0; s < nn; ++s)
+    if (S.sparent[s] >= nn) cut.push_back(s);
+  // split the heaviest piece at its root until there are 4 pieces per rank and none is heavier than
+  // half a rank's fair share (cf. the 1.2 imbalance target of anal.f90:284-459)
+  double total = 0.0;
+  for (int c : cut) total += W[c];
+  const size_t want = size_t(4 * S.nranks);
+  const double heavy = total / (2.0 * S.nranks);
+  for (;;) {
+    int best = -1;
+    for (size_t i = 0; i < cut.size(); ++i)
+      if (S.cptr[cut[i] + 1] > S.cptr[cut[i]] && (best < 0 || W[cut[i]] > W[cut[best]])) best = int(i);
+    if (best < 0) break;
+    if (cut.size() >= want && W[cut[best]] <= heavy) break;
+    const int s = cut[best];
+    cut.erase(cut.begin() + best);
+    top[s] = 1;
+    for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) cut.push_back(S.clist[ci]);
+  }
+  std::sort(cut.begin(), cut.end(), [&](int a, int b) { return W[a] != W[b] ? W[a] > W[b] : a < b; });
+  // the top part runs after the exchange, so it does not count against rank 0's share
+  std::vector<double> load(S.nranks, 0.0);
+  std::vector<int> rank_of_root(nn, -1);
+  for (int c : cut) {
+    int r = 0;
+    for (int k = 1; k < S.nranks; ++k)
+      if (load[k] < load[r]) r = k;
+    load[r] += W[c];
+    rank_of_root[c] = r;
+  }
+  // ownership flows down from the cut roots; the top part is -1
+  for (int s = nn - 1; s >= 0; --s) {
+    if (top[s]) S.owner[s] = -1;
+    else if (rank_of_root[s] >= 0) S.owner[s] = rank_of_root[s];
+    else S.owner[s] = S.owner[S.sparent[s]];
+  }
+  std::sort(cut.begin(), cut.end());
+  for (int c : cut)
+    if (S.sparent[c] < nn) S.cutroots.push_back(c);   // roots of the whole tree send nothing
+}
+
 }  // namespace gsls

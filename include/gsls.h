@@ -175,6 +175,33 @@ int gsls_enquire_indef(void* handle, int32_t* piv_order, double* d, gsls_inform*
 /* replaces ssids_alter(d, akeep, fkeep, options, inform)  src/ssids/ssids.f90:1347-1384 */
 int gsls_alter(void* handle, const double* d, gsls_inform* inform);
 
+/* ---- multi-GPU: elimination-tree sharding, one process (and one handle) per GPU -------------------
+ * replaces the reference's subtree partition over NUMA regions / GPUs, find_subtree_partition
+ * src/ssids/anal.f90:284-459 and the region assignment :569-590.  Every rank
+ * analyses the same matrix, then calls gsls_shard(nranks, rank): independent subtrees are dealt to the
+ * ranks, the remaining top of the tree belongs to rank 0.  The exchange steps between the phases are
+ * the caller's (RCCL all-reduce / broadcast on the buffers named below; galahad_amd/shard.py):
+ *   factor: phase 1 | SUM d_xchg[0:xchg_factor_elems) | phase 2
+ *   solve : phase 1 | SUM d_xchg[0:V) | phase 2 | BROADCAST d_xchg[0:n) from rank 0 | phase 3 |
+ *           SUM d_xchg[0:n) | phase 4           (d_xchg has xchg_solve_elems >= max(V, n) doubles)
+ * Every summed element is non-zero on exactly one rank, so the result is exact and independent of
+ * the reduction order.  inform of the factor phases carries THIS rank's num_neg / num_two / rank
+ * deficiency; add them over ranks.  Delayed pivots: a factor phase that leaves inform.num_delay > 0 on
+ * ANY rank has not completed; gather every rank's gsls_shard_failed list, hand the union to
+ * gsls_shard_repair on every rank (same elimination-order repair as gsls_factor, then re-analyse and
+ * re-shard; the exchange sizes may change) and start again at phase 1. */
+int gsls_shard(void* handle, int32_t nranks, int32_t rank, int64_t* xchg_factor_elems,
+               int64_t* xchg_solve_elems);
+int gsls_shard_factor_dev(void* handle, int32_t phase, int32_t posdef, const double* d_val, double* d_xchg,
+                          const gsls_options* options, gsls_inform* inform);
+int gsls_shard_solve_dev(void* handle, int32_t phase, double* d_x, double* d_xchg, gsls_inform* inform);
+#define GSLS_FAILCAP 16384
+int gsls_shard_failed(void* handle, int32_t* nfailed, int32_t* failed /* GSLS_FAILCAP */);
+int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed, int64_t* xchg_factor_elems,
+                      int64_t* xchg_solve_elems);
+/* the partition: owner[nnodes] (rank, -1 = top part), number of cut roots and their 1-based indices */
+int gsls_shard_get(void* handle, int32_t* owner, int32_t* ncut, int32_t* cutroots);
+
 /* ---- introspection used by the parity tests and bench (not part of the SSIDS surface) ------------ */
 
 /* symbolic factorization as the reference's akeep holds it (src/ssids/akeep.f90:25-76):
