@@ -135,17 +135,17 @@ def main():
     d_x = torch.empty_like(d_rhs)
     ginf = Inform()
 
-    ts = None
+    tsh = None
     if tree:
         from galahad_amd.shard import TreeShardedSLS
-        ts = TreeShardedSLS(s)
+        tsh = TreeShardedSLS(s)
 
     def step():
-        if ts is not None:
-            st = ts.factorize_dev(d_val, True)
+        if tsh is not None:
+            st = tsh.factorize_dev(d_val, True)
             assert st["flag"] == 0, st
             d_x.copy_(d_rhs)
-            ts.solve_dev(d_x)
+            tsh.solve_dev(d_x)
             return
         f = lib.gsls_factor_dev(s.handle, 1, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts), C.byref(ginf))
         assert f == 0, f
@@ -160,10 +160,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ksolve = []
-    tf = ts = 0.0
     for _ in range(a.steps):
         step()
-        tf += ginf.time_factor if False else 0.0
         kf, kd, kb = C.c_double(), C.c_double(), C.c_double()
         lib.gsls_last_solve_kernel_seconds(s.handle, C.byref(kf), C.byref(kd), C.byref(kb))
         ksolve.append(kf.value + kd.value + kb.value)
