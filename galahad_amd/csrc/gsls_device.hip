@@ -128,6 +128,13 @@ k_assemble_tile(const NodeDesc* __restrict__ nodes, const AsmTask* __restrict__ 
 // =================================================================================================
 constexpr int KC = 16;
 
+__device__ __forceinline__ double readlane_f64(double v, int k) {   // k wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+
 template <int AROWS>
 struct Stage {
   static constexpr int AST = AROWS + 16;  // == 16 mod 32 doubles: the two 16-lane halves of a
@@ -236,16 +243,30 @@ constexpr int PR = 128;  // panel rows handled by the diag kernel
 constexpr int LDP = PR + 1;  // LDS panel leading dimension (odd: column-strided access is conflict free)
 
 // ---- Cholesky flavour ----------------------------------------------------------------------------
+// The 128-row panel gets 64 extra rows holding the identity: the same block operations that turn A21
+// into L21 = A21 L11^-T turn them into L11^-T, which the panel kernel (and the solves) then use
+// instead of a 64-step substitution.  The 64 columns are factorized in four 16-column stages:
+//   a. wave 0: 16 x 16 Cholesky, one matrix row per lane in registers (static indices, 16 unrolled
+//      pivots, lane broadcasts through v_readlane); lanes 16-31 run the SAME instruction stream on the
+//      columns of the identity, which leaves them holding the inverse of the 16 x 16 factor;
+//   b. every row tile below:  Y = R * L16^-T            (MFMA, K = 16)
+//   c. trailing columns:      P -= Y_rows * Y_cols^T     (MFMA, K = 16)
+// i.e. 4 x (1 serial stage + 2 MFMA stages) instead of 64 barrier-separated pivots.
+constexpr int PRX = PR + NB;     // panel rows + identity rows
+constexpr int LDQ = PRX + 16;    // == 16 mod 32 doubles: conflict-free MFMA operand reads
+
 __global__ void __launch_bounds__(256)
 k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
-            double* __restrict__ L, int32_t* __restrict__ stat) {
+            double* __restrict__ L, double* __restrict__ Linv, int32_t* __restrict__ stat) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
-  double* P = reinterpret_cast<double*>(smem_raw);  // overlays the staging buffers after the GEMM
+  double* P = reinterpret_cast<double*>(smem_raw);  // [NB][LDQ], overlays the staging buffers after the GEMM
+  __shared__ double Xs[16 * 16];                    // Xs[k][n] = (L16^-1)[n][k]
 
   const PanelTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
   const int kb = t.step * NB;
   const int w = min(NB, nd.n - kb);
   const int pr = min(PR, nd.m - kb);
@@ -271,7 +292,6 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   __syncthreads();
   STAMP(1);
   {
-    const int lr = lane & 15, lq = lane >> 4;
     double g[2][4][4];   // all 32 loads in flight before the first LDS store
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -291,80 +311,97 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         for (int r = 0; r < 4; ++r) {
           const int row = 32 * wave + 16 * i + lq + 4 * r;
           const int col = 16 * j + lr;
-          P[col * LDP + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : 0.0;
+          // columns beyond the front's last one get a unit diagonal: they factorize to the identity
+          P[col * LDQ + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
         }
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int k = e & 63, n = e >> 6;
+      P[n * LDQ + PR + k] = (k == n) ? 1.0 : 0.0;
+    }
   }
   __syncthreads();
+  STAMP(2);
 
-  // ---- right-looking Cholesky of the 128 x w panel in LDS, two-level blocked.  Columns are kept
-  // UNscaled (a = l * sqrt(d)) until the final store, so neither sqrt nor a column scaling sits on the
-  // per-pivot critical path.  Micro-panels of 8 columns live in registers -- thread (r, h) owns row r
-  // of four of them, static register indices because the 8-pivot body is unrolled -- and each pivot
-  // costs one LDS column broadcast, one barrier, one reciprocal and <= 4 FMAs per thread; the other
-  // columns take one rank-8 update per micro-panel instead of eight rank-1 updates.
-  __shared__ double colb[8][PR];
-  __shared__ double fcol[8][NB];
-  __shared__ double rdv[8];
-  __shared__ double dpv[NB];
-  const int r = tid & (PR - 1), h = tid >> 7;
-  bool failed = false;
-  for (int jb = 0; jb < w; jb += 8) {
-    const int mb = min(8, w - jb);
-    double m4[4];
+  const int prup = (pr + 15) & ~15;
+  for (int jb = 0; jb < NB; jb += 16) {
+    // ---- a. 16 x 16 Cholesky + inverse, wave 0 ------------------------------------------------------
+    if (wave == 0) {
+      double v[16];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) m4[k] = (jb + 4 * h + k < NB) ? P[(jb + 4 * h + k) * LDP + r] : 0.0;
+      for (int k = 0; k < 16; ++k)
+        v[k] = (lane < 16) ? P[(jb + k) * LDQ + jb + lr] : ((lr == k) ? 1.0 : 0.0);
+      int failj = 16;
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      if (jj < mb) {
-        if (h == (jj >> 2)) colb[jj][r] = m4[jj & 3];
-        __syncthreads();
-        const double d = colb[jj][jb + jj];
-        if (!(d > 0.0)) {
-          if (tid == 0 && !failed) atomicMin(&stat[0], nd.sptr + kb + jb + jj);
-          failed = true;
+      for (int j = 0; j < 16; ++j) {
+        const double d = readlane_f64(v[j], j);
+        if (!(d > 0.0)) failj = min(failj, j);
+        double y = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware estimate + two Newton steps
+        const double hd = 0.5 * d;
+        y = y * fma(-hd * y, y, 1.5);
+        y = y * fma(-hd * y, y, 1.5);
+        v[j] *= y;                                   // L rows: l_rj (lane j: sqrt(d)); identity lanes: x_j
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = readlane_f64(v[j], k);
+          v[k] = fma(-v[j], lkj, v[k]);
         }
-        double rd = __builtin_amdgcn_rcp(d);        // reciprocal + two Newton steps: full precision
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        if (tid == 0) { rdv[jj] = rd; dpv[jb + jj] = d; }
-        const double lr = colb[jj][r] * rd;
+      }
+      if (lane == 0 && failj < 16 && jb + failj < w) atomicMin(&stat[0], nd.sptr + kb + jb + failj);
+      if (lane < 16) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (4 * h + k > jj) m4[k] -= lr * colb[jj][jb + 4 * h + k];
+        for (int k = 0; k < 16; ++k) P[(jb + k) * LDQ + jb + lr] = (k <= lr) ? v[k] : 0.0;
+      } else if (lane < 32) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Xs[lr * 16 + k] = (k >= lr) ? v[k] : 0.0;
       }
     }
     __syncthreads();
-    // multipliers of the trailing columns, and the finished micro-panel back to the LDS panel
-    for (int e = tid; e < 8 * NB; e += 256) {
-      const int jj = e >> 6, c2 = e & 63;
-      fcol[jj][c2] = (jj < mb && c2 >= jb + 8 && c2 < w) ? colb[jj][c2] * rdv[jj] : 0.0;
-    }
-    for (int e = tid; e < 8 * PR; e += 256) {
-      const int jj = e >> 7, rr = e & (PR - 1);
-      if (jj < mb) P[(jb + jj) * LDP + rr] = colb[jj][rr];
-    }
-    __syncthreads();
-    if (jb + 8 < w) {
-      double lrow[8];
+    // ---- b. rows below: Y = R * L16^-T, computed transposed so that lanes run along the rows of P ----
+    const int ntile = (PRX - jb - 16) / 16;
+    for (int tt = wave; tt < ntile; tt += 4) {
+      const int row0 = jb + 16 + 16 * tt;
+      if (row0 >= prup && row0 < PR) continue;       // rows past the end of the front
+      double4_t c = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) lrow[jj] = (jj < mb) ? colb[jj][r] : 0.0;
-      for (int c2 = jb + 8 + h; c2 < w; c2 += 2) {
-        double acc2 = P[c2 * LDP + r];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) acc2 -= lrow[jj] * fcol[jj][c2];
-        P[c2 * LDP + r] = acc2;
+      for (int k4 = 0; k4 < 16; k4 += 4) {
+        const double xa = Xs[(k4 + lq) * 16 + lr];                 // A[i=n][k]  = X[n][k]
+        const double rb = P[(jb + k4 + lq) * LDQ + row0 + lr];     // B[k][j=row] = R[row][k]
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, rb, c, 0, 0, 0);
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(jb + lq + 4 * r) * LDQ + row0 + lr] = c[r];
     }
     __syncthreads();
+    // ---- c. trailing columns of the block: P[rows, cols] -= Y[rows] Y[cols]^T ------------------------
+    if (jb + 16 < NB) {
+      int q = 0;
+      for (int col0 = jb + 16; col0 < NB; col0 += 16)
+        for (int row0 = col0; row0 < PRX; row0 += 16) {
+          if (row0 >= prup && row0 < PR) continue;
+          if ((q++ & 3) != wave) continue;
+          double4_t c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = P[(col0 + lq + 4 * r) * LDQ + row0 + lr];
+#pragma unroll
+          for (int k4 = 0; k4 < 16; k4 += 4) {
+            const double ya = -P[(jb + k4 + lq) * LDQ + col0 + lr];   // A[i=col][k]
+            const double yb = P[(jb + k4 + lq) * LDQ + row0 + lr];    // B[k][j=row]
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, yb, c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[(col0 + lq + 4 * r) * LDQ + row0 + lr] = c[r];
+        }
+      __syncthreads();
+    }
   }
-  // ---- scale by 1/sqrt(d) on the way out; the store to HBM is coalesced along rows ------------------
-  if (tid < w) fcol[0][tid] = sqrt(dpv[tid]);
-  __syncthreads();
+  STAMP(3);
+  // ---- store L (lower trapezoid) and W = L11^-T; both coalesced along rows ---------------------------
   for (int e = tid; e < pr * w; e += 256) {
     const int row = e % pr, col = e / pr;
-    if (row > col) Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDP + row] / fcol[0][col];
-    else if (row == col) Lb[int64_t(kb + col) * nd.ld + kb + row] = fcol[0][col];
+    if (row >= col) Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDQ + row];
   }
+  double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
+  for (int e = tid; e < NB * NB; e += 256) W[e] = P[(e >> 6) * LDQ + PR + (e & 63)];
 }
 
 // ---- LDL^T flavour: complete pivoting (1x1 and 2x2) inside the w x w diagonal block, applied to the
@@ -800,6 +837,111 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
 }
 
 // =================================================================================================
+// panel kernel, Cholesky flavour: row chunk c>=1 of block column `step`
+//   R = (A - L[rows,0:kb] L[kb:kb+w,0:kb]^T) * W,   W = L11^-T from the diag kernel
+// both products on the matrix cores; no substitution loop.
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_panel_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
+             double* __restrict__ L, const double* __restrict__ Linv) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
+  double* Pc = reinterpret_cast<double*>(smem_raw);                  // [k][RBP]: R'[row][k]
+  double* Ws = reinterpret_cast<double*>(smem_raw) + NB * RBP;       // [n][RBP]: X[n][k] = W[k + 64 n]
+
+  const PanelTask t = tasks[blockIdx.x];
+  const NodeDesc nd = nodes[t.node];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int kb = t.step * NB;
+  const int w = min(NB, nd.n - kb);
+  const int r0 = kb + PR + (t.chunk - 1) * RB;
+  const int rows = min(RB, nd.m - r0);
+  double* Lb = L + nd.loff;
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
+  if (kb > 0) {
+    StageRegs<RB> rg;
+    stage_load<RB>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, 0, kb, nullptr, tid);
+    for (int k0 = 0; k0 < kb; k0 += KC) {
+      __syncthreads();
+      stage_store<RB>(sg, rg, tid);
+      __syncthreads();
+      if (k0 + KC < kb) stage_load<RB>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, k0 + KC, kb, nullptr, tid);
+      mfma_panel<RB, 2, 2>(sg, wr, wc, lane, acc);
+    }
+  }
+  __syncthreads();
+  {
+    double g[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr + 16 * i + lq + 4 * r;
+          const int col = wc + 16 * j + lr;
+          g[i][j][r] = (row < rows && col < w) ? Lb[int64_t(kb + col) * nd.ld + r0 + row] : 0.0;
+        }
+    const double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
+    double wv[16];
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) wv[tt] = W[tid + 256 * tt];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr + 16 * i + lq + 4 * r;
+          const int col = wc + 16 * j + lr;
+          Pc[col * RBP + row] = (row < rows && col < w) ? g[i][j][r] - acc[i][j][r] : 0.0;
+        }
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+      const int e = tid + 256 * tt;
+      Ws[(e >> 6) * RBP + (e & 63)] = wv[tt];
+    }
+  }
+  __syncthreads();
+  // Y^T = X R'^T: wave -> 16 rows of the chunk, all four column tiles; X is lower triangular, so
+  // column tile ct only needs k < 16 (ct + 1)
+  {
+    const int row0 = 16 * wave;
+    double4_t y[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) y[ct] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < NB; k4 += 4) {
+      const double rb = Pc[(k4 + lq) * RBP + row0 + lr];            // B[k][j=row] = R'[row][k]
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        if (k4 < 16 * (ct + 1)) {
+          const double xa = Ws[(16 * ct + lr) * RBP + k4 + lq];     // A[i=c][k] = X[c][k]
+          y[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, rb, y[ct], 0, 0, 0);
+        }
+      }
+    }
+    const int row = row0 + lr;
+    if (row < rows) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * ct + lq + 4 * r;
+          if (c < w) Lb[int64_t(kb + c) * nd.ld + r0 + row] = y[ct][r];
+        }
+    }
+  }
+}
+
+// =================================================================================================
 // contribution kernel: tile (ti,tj) of  C -= L21 * D * L21^T   (K = n, MFMA)
 // =================================================================================================
 template <bool POSDEF>
@@ -882,12 +1024,6 @@ __global__ void k_permute_out(int n, const int32_t* __restrict__ invp, const dou
 // owns row i (forward) or column i (backward) in registers and the 64 dependent steps are a
 // v_readlane/shuffle + one FMA each: no memory access and no barrier inside the recurrence.
 constexpr int SB = 65;
-
-__device__ __forceinline__ double readlane_f64(double v, int k) {   // k wave-uniform
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-  return __hiloint2double(hi, lo);
-}
 
 template <bool UNIT>
 __device__ __forceinline__ double wave_trsv_fwd(const double* blk, int nb, int lane, double yv) {
@@ -1353,7 +1489,7 @@ void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.asmtasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.segC, F.segV, F.posowner};
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.segC, F.segV, F.posowner};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -1361,9 +1497,9 @@ void dev_free(DeviceFactor& F) {
 
 static hipError_t allow_big_lds() {
   const int big = 160 * 1024 - 512;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1379,6 +1515,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(allow_big_lds());
   const int nn = S.nnodes;
   std::vector<NodeDesc> nd(nn);
+  int64_t nblk64 = 0;   // 64-column blocks, numbered front by front: slots of the L11^-T arena
   for (int s = 0; s < nn; ++s) {
     NodeDesc& d = nd[s];
     d.m = S.nrow(s);
@@ -1388,7 +1525,8 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     d.cbeg = S.cptr[s];
     d.cend = S.cptr[s + 1];
     d.parent = S.sparent[s];
-    d.pad = 0;
+    d.iblk = int32_t(nblk64);
+    nblk64 += (S.ncol(s) + NB - 1) / NB;
     d.loff = S.loff[s];
     d.coff = S.coff[s];
     d.roff = S.rptr[s];
@@ -1581,6 +1719,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(upload(F.ttasks, tt, st));
   HIPCHK(upload(F.invp, S.invp, st));
   F.nscatter = nz;
+  F.nblk64 = nblk64;
   F.L_elems = S.loff[nn];
   F.C_elems = S.coff[nn];
   F.cvec_elems = S.cmapptr[nn];
@@ -1601,6 +1740,8 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
                                 double small, double u, hipStream_t st) {
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
+  const size_t lds_chol = std::max(sizeof(Stage<PR>), sizeof(double) * LDQ * NB);
+  const size_t lds_pchol = std::max(sizeof(Stage<RB>), sizeof(double) * (2 * NB * RBP));
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
     for (int rk = 0; rk < ASM_RANKS; ++rk)
@@ -1614,21 +1755,32 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
         if (POSDEF)
-          hipLaunchKernelGGL(k_diag_chol, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s], F.L, F.stat);
+          hipLaunchKernelGGL(k_diag_chol, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_chol, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.stat);
         else
           hipLaunchKernelGGL(k_diag_ldlt, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
                              F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, F.faillist, small, u);
       }
-      if (lp.panel_cnt[2 * s + 1] > 0)
-        hipLaunchKernelGGL(k_panel<POSDEF>, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_panel, st,
-                           F.nodes, F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u);
+      if (lp.panel_cnt[2 * s + 1] > 0) {
+        if (POSDEF)
+          hipLaunchKernelGGL(k_panel_chol, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_pchol, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.Linv);
+        else
+          hipLaunchKernelGGL(k_panel<false>, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_panel, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u);
+      }
     }
     if (lp.tile_cnt > 0)
       hipLaunchKernelGGL(k_contrib<POSDEF>, dim3(lp.tile_cnt), dim3(256), 0, st, F.nodes,
                          F.ttasks + lp.tile_begin, F.L, F.D, F.C);
   }
   return hipGetLastError();
+}
+
+// arena of the L11^-T blocks the Cholesky kernels exchange (one 64 x 64 block per 64 pivots)
+static hipError_t ensure_linv(DeviceFactor& F) {
+  if (F.Linv) return hipSuccess;
+  return hipMalloc(reinterpret_cast<void**>(&F.Linv), std::max<int64_t>(F.nblk64, 1) * NB * NB * sizeof(double));
 }
 
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
@@ -1644,7 +1796,10 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
     hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, F.nscatter, F.asrc, F.adst, d_val,
                        F.L, d_scale, F.arow, F.acol, F.invp);
   }
-  if (posdef) return factor_levels<true>(S, F, F.plan, small, u, st);
+  if (posdef) {
+    HIPCHK(ensure_linv(F));
+    return factor_levels<true>(S, F, F.plan, small, u, st);
+  }
   return factor_levels<false>(S, F, F.plan, small, u, st);
 }
 
@@ -1768,6 +1923,7 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
       hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, F.nscatter, F.asrc, F.adst, d_val, F.L,
                          static_cast<const double*>(nullptr), F.arow, F.acol, F.invp);
     }
+    if (posdef) HIPCHK(ensure_linv(F));
     hipError_t e = posdef ? factor_levels<true>(S, F, F.planA, small, u, st)
                           : factor_levels<false>(S, F, F.planA, small, u, st);
     if (e != hipSuccess) return e;

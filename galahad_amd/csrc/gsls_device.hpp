@@ -22,7 +22,7 @@ constexpr int ASM_RANKS = 4;  // children of a parent assembled by tiled launche
 struct NodeDesc {
   int32_t m, n, ld, sptr;      // sptr = first pivot position of the node
   int32_t cbeg, cend;          // children in clist[cbeg..cend)
-  int32_t parent, pad;
+  int32_t parent, iblk;        // iblk = index of the node's first 64-column block (L11^-T arena)
   int64_t loff, coff;
   int64_t roff;                // offset of the node's row list in rlist
   int64_t moff;                // offset of the node's (m-n) child->parent map / contribution vector
@@ -90,6 +90,8 @@ struct DeviceFactor {
   int32_t* posowner = nullptr;    // pivot position -> owner rank of its front (-1 top)
   // numeric
   double* L = nullptr;
+  double* Linv = nullptr;        // Cholesky only: L11^-T of every 64-column block, nblk64 x 64 x 64
+  int64_t nblk64 = 0;
   double* C = nullptr;         // contribution arena
   double* D = nullptr;         // 2*n inverted pivots in pivot order (indefinite)
   double* val = nullptr;       // staging for host-supplied values
