@@ -135,21 +135,23 @@ __device__ __forceinline__ double readlane_f64(double v, int k) {   // k wave-un
 }
 
 
-template <int AROWS>
+template <int AROWS, int KCH = KC>
 struct Stage {
   static constexpr int AST = AROWS + 16;  // == 16 mod 32 doubles: the two 16-lane halves of a
   static constexpr int BST = 64 + 16;     // ds_read_b64 lane group land on disjoint banks
-  double As[KC][AST];
-  double Bs[KC][BST];
+  double As[KCH][AST];
+  double Bs[KCH][BST];
 };
 
 // MT x NT 16x16 tiles per wave at (rbase, cbase) of the staged panels
-template <int AROWS, int MT, int NT>
-__device__ __forceinline__ void mfma_panel(const Stage<AROWS>& sg, int rbase, int cbase, int lane,
+// TRANS: the tile is produced transposed (acc[i][j][r] = C[col = 16j + (l>>4) + 4r][row = 16i + (l&15)]), i.e.
+// lanes run along the ROWS of the front: coalesced / conflict-free epilogues for column-major storage
+template <int AROWS, int MT, int NT, int KCH = KC, bool TRANS = false>
+__device__ __forceinline__ void mfma_panel(const Stage<AROWS, KCH>& sg, int rbase, int cbase, int lane,
                                            double4_t (&acc)[MT][NT]) {
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-  for (int k4 = 0; k4 < KC; k4 += 4) {
+  for (int k4 = 0; k4 < KCH; k4 += 4) {
     double a[MT], b[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) a[i] = sg.As[k4 + lk][rbase + 16 * i + lr];
@@ -159,7 +161,8 @@ __device__ __forceinline__ void mfma_panel(const Stage<AROWS>& sg, int rbase, in
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[i][j], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
@@ -174,17 +177,17 @@ __device__ __forceinline__ void mfma_panel(const Stage<AROWS>& sg, int rbase, in
 //                dinv != nullptr the B panel is (L*D): D is held inverted, 1x1 as [d,0], 2x2 as
 //                [d11,d21,inf,d22] (ldlt_app.cxx:324-329); L*D as in calc_ld.hxx:43-118.
 //   stage_store: registers -> LDS.
-template <int AROWS>
+template <int AROWS, int KCH = KC>
 struct StageRegs {
-  double va[AROWS * KC / 256];
-  double vb[64 * KC / 256];
+  double va[AROWS * KCH / 256];
+  double vb[64 * KCH / 256];
 };
 
-template <int AROWS>
-__device__ __forceinline__ void stage_load(StageRegs<AROWS>& rg, const double* __restrict__ Lb, int ld,
+template <int AROWS, int KCH = KC>
+__device__ __forceinline__ void stage_load(StageRegs<AROWS, KCH>& rg, const double* __restrict__ Lb, int ld,
                                            int arow0, int amax, int brow0, int bmax, int k0, int kmax,
                                            const double* __restrict__ dinv, int tid) {
-  constexpr int NA = AROWS * KC / 256, NBL = 64 * KC / 256;
+  constexpr int NA = AROWS * KCH / 256, NBL = 64 * KCH / 256;
 #pragma unroll
   for (int t = 0; t < NA; ++t) {
     const int e = tid + 256 * t;
@@ -217,9 +220,9 @@ __device__ __forceinline__ void stage_load(StageRegs<AROWS>& rg, const double* _
   }
 }
 
-template <int AROWS>
-__device__ __forceinline__ void stage_store(Stage<AROWS>& sg, const StageRegs<AROWS>& rg, int tid) {
-  constexpr int NA = AROWS * KC / 256, NBL = 64 * KC / 256;
+template <int AROWS, int KCH = KC>
+__device__ __forceinline__ void stage_store(Stage<AROWS, KCH>& sg, const StageRegs<AROWS, KCH>& rg, int tid) {
+  constexpr int NA = AROWS * KCH / 256, NBL = 64 * KCH / 256;
 #pragma unroll
   for (int t = 0; t < NA; ++t) {
     const int e = tid + 256 * t;
@@ -252,14 +255,43 @@ constexpr int LDP = PR + 1;  // LDS panel leading dimension (odd: column-strided
 //   b. every row tile below:  Y = R * L16^-T            (MFMA, K = 16)
 //   c. trailing columns:      P -= Y_rows * Y_cols^T     (MFMA, K = 16)
 // i.e. 4 x (1 serial stage + 2 MFMA stages) instead of 64 barrier-separated pivots.
+constexpr int CK = 32;           // K chunk of the Cholesky kernels' left-looking updates
 constexpr int PRX = PR + NB;     // panel rows + identity rows
 constexpr int LDQ = PRX + 16;    // == 16 mod 32 doubles: conflict-free MFMA operand reads
+
+// P[row tile rt, col tiles cj0 .. cj0+NC) -= Y[rt] Y[cj]^T with Y = columns jb..jb+16 of the LDS panel
+template <int NC>
+__device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int cj0, int lr, int lq) {
+  const int row0 = 16 * rt;
+  double yb[4], ya[NC][4];
+  double4_t c[NC];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) yb[k] = P[(jb + 4 * k + lq) * ldq + row0 + lr];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    const int col0 = 16 * (cj0 + q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ya[q][k] = -P[(jb + 4 * k + lq) * ldq + col0 + lr];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[q][r] = P[(col0 + lq + 4 * r) * ldq + row0 + lr];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q][k], yb[k], c[q], 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    const int col0 = 16 * (cj0 + q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P[(col0 + lq + 4 * r) * ldq + row0 + lr] = c[q][r];
+  }
+}
 
 __global__ void __launch_bounds__(256)
 k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
             double* __restrict__ L, double* __restrict__ Linv, int32_t* __restrict__ stat) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
+  Stage<PR, CK>& sg = *reinterpret_cast<Stage<PR, CK>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);  // [NB][LDQ], overlays the staging buffers after the GEMM
   __shared__ double Xs[16 * 16];                    // Xs[k][n] = (L16^-1)[n][k]
 
@@ -273,128 +305,140 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   double* Lb = L + nd.loff;
 
   STAMP(0);
+  // the block's own entries first: their latency hides behind the left-looking update.  Tiles are
+  // produced transposed (lanes along the rows of the front), so these loads are 128-byte segments
+  // and the LDS panel is written without bank conflicts.
+  double g[2][4][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * wave + 16 * i + lr;
+        const int col = 16 * j + lq + 4 * r;
+        g[i][j][r] = (row < pr && col < w) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
+      }
   double4_t acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
   if (kb > 0) {
-    StageRegs<PR> rg;
-    stage_load<PR>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, 0, kb, nullptr, tid);
-    for (int k0 = 0; k0 < kb; k0 += KC) {
+    StageRegs<PR, CK> rg;
+    stage_load<PR, CK>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, 0, kb, nullptr, tid);
+    for (int k0 = 0; k0 < kb; k0 += CK) {
       __syncthreads();
-      stage_store<PR>(sg, rg, tid);
+      stage_store<PR, CK>(sg, rg, tid);
       __syncthreads();
-      if (k0 + KC < kb) stage_load<PR>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0 + KC, kb, nullptr, tid);
-      mfma_panel<PR, 2, 4>(sg, 32 * wave, 0, lane, acc);
+      if (k0 + CK < kb) stage_load<PR, CK>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0 + CK, kb, nullptr, tid);
+      mfma_panel<PR, 2, 4, CK, true>(sg, 32 * wave, 0, lane, acc);
     }
   }
   __syncthreads();
   STAMP(1);
-  {
-    double g[2][4][4];   // all 32 loads in flight before the first LDS store
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 32 * wave + 16 * i + lq + 4 * r;
-          const int col = 16 * j + lr;
-          g[i][j][r] = (row < pr && col < w) ? Lb[int64_t(kb + col) * nd.ld + kb + row] : 0.0;
-        }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 32 * wave + 16 * i + lq + 4 * r;
-          const int col = 16 * j + lr;
-          // columns beyond the front's last one get a unit diagonal: they factorize to the identity
-          P[col * LDQ + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
-        }
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int k = e & 63, n = e >> 6;
-      P[n * LDQ + PR + k] = (k == n) ? 1.0 : 0.0;
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * wave + 16 * i + lr;
+        const int col = 16 * j + lq + 4 * r;
+        // columns beyond the front's last one get a unit diagonal: they factorize to the identity
+        P[col * LDQ + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
+      }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int k = e & 63, n = e >> 6;
+    P[n * LDQ + PR + k] = (k == n) ? 1.0 : 0.0;
   }
   __syncthreads();
   STAMP(2);
 
-  const int prup = (pr + 15) & ~15;
+  // ---- a. 16 x 16 Cholesky + inverse of the diagonal block at jb (one wave) --------------------------
+  auto chol16 = [&](int jb) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      v[k] = (lane < 16) ? P[(jb + k) * LDQ + jb + lr] : ((lr == k) ? 1.0 : 0.0);
+    int failj = 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double d = readlane_f64(v[j], j);
+      if (!(d > 0.0)) failj = min(failj, j);
+      double y = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware estimate + two Newton steps
+      const double hd = 0.5 * d;
+      y = y * fma(-hd * y, y, 1.5);
+      y = y * fma(-hd * y, y, 1.5);
+      v[j] *= y;                                   // L rows: l_rj (lane j: sqrt(d)); identity lanes: x_j
+#pragma unroll
+      for (int k = j + 1; k < 16; ++k) {
+        const double lkj = readlane_f64(v[j], k);
+        v[k] = fma(-v[j], lkj, v[k]);
+      }
+    }
+    if (lane == 0 && failj < 16 && jb + failj < w) atomicMin(&stat[0], nd.sptr + kb + jb + failj);
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) P[(jb + k) * LDQ + jb + lr] = (k <= lr) ? v[k] : 0.0;
+    } else if (lane < 32) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) Xs[lr * 16 + k] = (k >= lr) ? v[k] : 0.0;
+    }
+  };
+  if (wave == 0) chol16(0);
+  __syncthreads();
   for (int jb = 0; jb < NB; jb += 16) {
-    // ---- a. 16 x 16 Cholesky + inverse, wave 0 ------------------------------------------------------
-    if (wave == 0) {
-      double v[16];
+    STAMP(4 + 3 * (jb >> 4));
+    // ---- b. rows below: Y = R * L16^-T, computed transposed so that lanes run along the rows of P.
+    // Three row tiles per wave, no branches around the MFMAs: a tile index past the end is clamped to
+    // the last tile (computed again, not stored).
+    {
+      const int rt0 = (jb >> 4) + 1;
+      double4_t c[3];
+      double rb[3][4], xa[4];
+      int rtc[3];
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        v[k] = (lane < 16) ? P[(jb + k) * LDQ + jb + lr] : ((lr == k) ? 1.0 : 0.0);
-      int failj = 16;
+      for (int k = 0; k < 4; ++k) xa[k] = Xs[(4 * k + lq) * 16 + lr];                  // A[i=n][k] = X[n][k]
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double d = readlane_f64(v[j], j);
-        if (!(d > 0.0)) failj = min(failj, j);
-        double y = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware estimate + two Newton steps
-        const double hd = 0.5 * d;
-        y = y * fma(-hd * y, y, 1.5);
-        y = y * fma(-hd * y, y, 1.5);
-        v[j] *= y;                                   // L rows: l_rj (lane j: sqrt(d)); identity lanes: x_j
+      for (int i = 0; i < 3; ++i) {
+        rtc[i] = min(rt0 + wave + 4 * i, PRX / 16 - 1);
+        c[i] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-          const double lkj = readlane_f64(v[j], k);
-          v[k] = fma(-v[j], lkj, v[k]);
+        for (int k = 0; k < 4; ++k) rb[i][k] = P[(jb + 4 * k + lq) * LDQ + 16 * rtc[i] + lr];   // B[k][j=row]
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k], rb[i][k], c[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (rt0 + wave + 4 * i < PRX / 16) {      // a clamped duplicate must not store: its inputs may be gone
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[(jb + lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = c[i][r];
         }
-      }
-      if (lane == 0 && failj < 16 && jb + failj < w) atomicMin(&stat[0], nd.sptr + kb + jb + failj);
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) P[(jb + k) * LDQ + jb + lr] = (k <= lr) ? v[k] : 0.0;
-      } else if (lane < 32) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) Xs[lr * 16 + k] = (k >= lr) ? v[k] : 0.0;
-      }
     }
     __syncthreads();
-    // ---- b. rows below: Y = R * L16^-T, computed transposed so that lanes run along the rows of P ----
-    const int ntile = (PRX - jb - 16) / 16;
-    for (int tt = wave; tt < ntile; tt += 4) {
-      const int row0 = jb + 16 + 16 * tt;
-      if (row0 >= prup && row0 < PR) continue;       // rows past the end of the front
-      double4_t c = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int k4 = 0; k4 < 16; k4 += 4) {
-        const double xa = Xs[(k4 + lq) * 16 + lr];                 // A[i=n][k]  = X[n][k]
-        const double rb = P[(jb + k4 + lq) * LDQ + row0 + lr];     // B[k][j=row] = R[row][k]
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, rb, c, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P[(jb + lq + 4 * r) * LDQ + row0 + lr] = c[r];
-    }
-    __syncthreads();
-    // ---- c. trailing columns of the block: P[rows, cols] -= Y[rows] Y[cols]^T ------------------------
+    STAMP(5 + 3 * (jb >> 4));
     if (jb + 16 < NB) {
-      int q = 0;
-      for (int col0 = jb + 16; col0 < NB; col0 += 16)
-        for (int row0 = col0; row0 < PRX; row0 += 16) {
-          if (row0 >= prup && row0 < PR) continue;
-          if ((q++ & 3) != wave) continue;
-          double4_t c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) c[r] = P[(col0 + lq + 4 * r) * LDQ + row0 + lr];
-#pragma unroll
-          for (int k4 = 0; k4 < 16; k4 += 4) {
-            const double ya = -P[(jb + k4 + lq) * LDQ + col0 + lr];   // A[i=col][k]
-            const double yb = P[(jb + k4 + lq) * LDQ + row0 + lr];    // B[k][j=row]
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, yb, c, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) P[(col0 + lq + 4 * r) * LDQ + row0 + lr] = c[r];
+      // ---- c1. the next block column only, all waves ------------------------------------------------
+      const int cj1 = (jb >> 4) + 1;
+      for (int rt = cj1 + wave; rt < PRX / 16; rt += 4) syrk_row<1>(P, LDQ, jb, rt, cj1, lr, lq);
+      __syncthreads();
+      // ---- wave 0 factorizes the next diagonal block while the others finish the trailing update -----
+      if (wave == 0) {
+        chol16(jb + 16);
+      } else if (cj1 + 1 < NB / 16) {
+        for (int rt = cj1 + wave; rt < PRX / 16; rt += 3) {
+          if (min(NB / 16 - 1, rt) - cj1 == 2) syrk_row<2>(P, LDQ, jb, rt, cj1 + 1, lr, lq);
+          else syrk_row<1>(P, LDQ, jb, rt, cj1 + 1, lr, lq);
         }
+      }
       __syncthreads();
     }
+    STAMP(6 + 3 * (jb >> 4));
   }
-  STAMP(3);
+  STAMP(16);
   // ---- store L (lower trapezoid) and W = L11^-T; both coalesced along rows ---------------------------
   for (int e = tid; e < pr * w; e += 256) {
     const int row = e % pr, col = e / pr;
@@ -402,6 +446,7 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   }
   double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
   for (int e = tid; e < NB * NB; e += 256) W[e] = P[(e >> 6) * LDQ + PR + (e & 63)];
+  STAMP(17);
 }
 
 // ---- LDL^T flavour: complete pivoting (1x1 and 2x2) inside the w x w diagonal block, applied to the
@@ -845,7 +890,7 @@ __global__ void __launch_bounds__(256)
 k_panel_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
              double* __restrict__ L, const double* __restrict__ Linv) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
+  Stage<RB, CK>& sg = *reinterpret_cast<Stage<RB, CK>*>(smem_raw);
   double* Pc = reinterpret_cast<double*>(smem_raw);                  // [k][RBP]: R'[row][k]
   double* Ws = reinterpret_cast<double*>(smem_raw) + NB * RBP;       // [n][RBP]: X[n][k] = W[k + 64 n]
 
@@ -859,55 +904,54 @@ k_panel_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ t
   const int rows = min(RB, nd.m - r0);
   double* Lb = L + nd.loff;
 
+  // this chunk's own entries and W first, so that their latency hides behind the left-looking update
+  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
+  double g[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr + 16 * i + lr;
+        const int col = wc + 16 * j + lq + 4 * r;
+        g[i][j][r] = (row < rows && col < w) ? Lb[int64_t(kb + col) * nd.ld + r0 + row] : 0.0;
+      }
+  const double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);   // written by this step's diag kernel
+  double wv[16];
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) wv[tt] = W[tid + 256 * tt];
   double4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
   if (kb > 0) {
-    StageRegs<RB> rg;
-    stage_load<RB>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, 0, kb, nullptr, tid);
-    for (int k0 = 0; k0 < kb; k0 += KC) {
+    StageRegs<RB, CK> rg;
+    stage_load<RB, CK>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, 0, kb, nullptr, tid);
+    for (int k0 = 0; k0 < kb; k0 += CK) {
       __syncthreads();
-      stage_store<RB>(sg, rg, tid);
+      stage_store<RB, CK>(sg, rg, tid);
       __syncthreads();
-      if (k0 + KC < kb) stage_load<RB>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, k0 + KC, kb, nullptr, tid);
-      mfma_panel<RB, 2, 2>(sg, wr, wc, lane, acc);
+      if (k0 + CK < kb) stage_load<RB, CK>(rg, Lb, nd.ld, r0, nd.m, kb, kb + w, k0 + CK, kb, nullptr, tid);
+      mfma_panel<RB, 2, 2, CK, true>(sg, wr, wc, lane, acc);
     }
   }
   __syncthreads();
-  {
-    double g[2][2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wr + 16 * i + lq + 4 * r;
-          const int col = wc + 16 * j + lr;
-          g[i][j][r] = (row < rows && col < w) ? Lb[int64_t(kb + col) * nd.ld + r0 + row] : 0.0;
-        }
-    const double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
-    double wv[16];
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr + 16 * i + lr;
+        const int col = wc + 16 * j + lq + 4 * r;
+        Pc[col * RBP + row] = (row < rows && col < w) ? g[i][j][r] - acc[i][j][r] : 0.0;
+      }
 #pragma unroll
-    for (int tt = 0; tt < 16; ++tt) wv[tt] = W[tid + 256 * tt];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wr + 16 * i + lq + 4 * r;
-          const int col = wc + 16 * j + lr;
-          Pc[col * RBP + row] = (row < rows && col < w) ? g[i][j][r] - acc[i][j][r] : 0.0;
-        }
-#pragma unroll
-    for (int tt = 0; tt < 16; ++tt) {
-      const int e = tid + 256 * tt;
-      Ws[(e >> 6) * RBP + (e & 63)] = wv[tt];
-    }
+  for (int tt = 0; tt < 16; ++tt) {
+    const int e = tid + 256 * tt;
+    Ws[(e >> 6) * RBP + (e & 63)] = wv[tt];
   }
   __syncthreads();
   // Y^T = X R'^T: wave -> 16 rows of the chunk, all four column tiles; X is lower triangular, so
@@ -948,7 +992,7 @@ template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks,
           const double* __restrict__ L, const double* __restrict__ D, double* __restrict__ C) {
-  __shared__ Stage<TS> sg;
+  __shared__ Stage<TS, CK> sg;
   const TileTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -956,46 +1000,48 @@ k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks
   const double* Lb = L + nd.loff;
   const double* dinv = POSDEF ? nullptr : (D + 2 * int64_t(nd.sptr));
   const int ar0 = nd.n + t.ti * TS, br0 = nd.n + t.tj * TS;
+  double* Cb = C + nd.coff;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
 
+  // tiles are produced transposed: lanes run along the rows of C (column-major), so the
+  // read-modify-write of the contribution block moves 128-byte segments; its loads go first
+  double cv[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = t.ti * TS + wr + 16 * i + lr;
+        const int col = t.tj * TS + wc + 16 * j + lq + 4 * r;
+        cv[i][j][r] = (row < cm && col < cm && row >= col) ? Cb[int64_t(col) * cm + row] : 0.0;
+      }
   double4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
   {
-    StageRegs<TS> rg;
-    stage_load<TS>(rg, Lb, nd.ld, ar0, nd.m, br0, nd.m, 0, nd.n, dinv, tid);
-    for (int k0 = 0; k0 < nd.n; k0 += KC) {
+    StageRegs<TS, CK> rg;
+    stage_load<TS, CK>(rg, Lb, nd.ld, ar0, nd.m, br0, nd.m, 0, nd.n, dinv, tid);
+    for (int k0 = 0; k0 < nd.n; k0 += CK) {
       __syncthreads();
-      stage_store<TS>(sg, rg, tid);
+      stage_store<TS, CK>(sg, rg, tid);
       __syncthreads();
-      if (k0 + KC < nd.n) stage_load<TS>(rg, Lb, nd.ld, ar0, nd.m, br0, nd.m, k0 + KC, nd.n, dinv, tid);
-      mfma_panel<TS, 2, 2>(sg, wr, wc, lane, acc);
+      if (k0 + CK < nd.n) stage_load<TS, CK>(rg, Lb, nd.ld, ar0, nd.m, br0, nd.m, k0 + CK, nd.n, dinv, tid);
+      mfma_panel<TS, 2, 2, CK, true>(sg, wr, wc, lane, acc);
     }
   }
-  double* Cb = C + nd.coff;
-  const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = t.ti * TS + wr + 16 * i + lq + 4 * r;
-        const int col = t.tj * TS + wc + 16 * j + lr;
-        const bool ok = (row < cm && col < cm && row >= col);
-        acc[i][j][r] = (ok ? Cb[int64_t(col) * cm + row] : 0.0) - acc[i][j][r];
-      }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = t.ti * TS + wr + 16 * i + lq + 4 * r;
-        const int col = t.tj * TS + wc + 16 * j + lr;
-        if (row < cm && col < cm && row >= col) Cb[int64_t(col) * cm + row] = acc[i][j][r];
+        const int row = t.ti * TS + wr + 16 * i + lr;
+        const int col = t.tj * TS + wc + 16 * j + lq + 4 * r;
+        if (row < cm && col < cm && row >= col) Cb[int64_t(col) * cm + row] = cv[i][j][r] - acc[i][j][r];
       }
 }
 
@@ -1740,8 +1786,8 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
                                 double small, double u, hipStream_t st) {
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
-  const size_t lds_chol = std::max(sizeof(Stage<PR>), sizeof(double) * LDQ * NB);
-  const size_t lds_pchol = std::max(sizeof(Stage<RB>), sizeof(double) * (2 * NB * RBP));
+  const size_t lds_chol = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * NB);
+  const size_t lds_pchol = std::max(sizeof(Stage<RB, CK>), sizeof(double) * (2 * NB * RBP));
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
     for (int rk = 0; rk < ASM_RANKS; ++rk)

@@ -1,4 +1,5 @@
-import sys, ctypes as C; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys, os, ctypes as C
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import numpy as np, problems as P
 from galahad_amd import SLS, SMT, Control, InformSLS
 import galahad_amd._lib as L
