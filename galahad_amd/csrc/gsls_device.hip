@@ -261,7 +261,7 @@ constexpr int LDQ = PRX + 16;    // == 16 mod 32 doubles: conflict-free MFMA ope
 
 // P[row tile rt, col tiles cj0 .. cj0+NC) -= Y[rt] Y[cj]^T with Y = columns jb..jb+16 of the LDS panel
 template <int NC>
-__device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int cj0, int lr, int lq) {
+__device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int cj0, int w, int lr, int lq) {
   const int row0 = 16 * rt;
   double yb[4], ya[NC][4];
   double4_t c[NC];
@@ -271,7 +271,8 @@ __device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int
   for (int q = 0; q < NC; ++q) {
     const int col0 = 16 * (cj0 + q);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ya[q][k] = -P[(jb + 4 * k + lq) * ldq + col0 + lr];
+    // columns >= w are padding (unit diagonal): they must not see the real rows' updates
+    for (int k = 0; k < 4; ++k) ya[q][k] = (col0 + lr < w) ? -P[(jb + 4 * k + lq) * ldq + col0 + lr] : 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) c[q][r] = P[(col0 + lq + 4 * r) * ldq + row0 + lr];
   }
@@ -371,9 +372,11 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       y = y * fma(-hd * y, y, 1.5);
       y = y * fma(-hd * y, y, 1.5);
       v[j] *= y;                                   // L rows: l_rj (lane j: sqrt(d)); identity lanes: x_j
+      // columns >= w are padding (unit diagonal): rows >= w keep their l_rj but must not update them
+      const double u = (jb + lr < w) ? v[j] : 0.0;
 #pragma unroll
       for (int k = j + 1; k < 16; ++k) {
-        const double lkj = readlane_f64(v[j], k);
+        const double lkj = readlane_f64(u, k);
         v[k] = fma(-v[j], lkj, v[k]);
       }
     }
@@ -423,15 +426,15 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     if (jb + 16 < NB) {
       // ---- c1. the next block column only, all waves ------------------------------------------------
       const int cj1 = (jb >> 4) + 1;
-      for (int rt = cj1 + wave; rt < PRX / 16; rt += 4) syrk_row<1>(P, LDQ, jb, rt, cj1, lr, lq);
+      for (int rt = cj1 + wave; rt < PRX / 16; rt += 4) syrk_row<1>(P, LDQ, jb, rt, cj1, w, lr, lq);
       __syncthreads();
       // ---- wave 0 factorizes the next diagonal block while the others finish the trailing update -----
       if (wave == 0) {
         chol16(jb + 16);
       } else if (cj1 + 1 < NB / 16) {
         for (int rt = cj1 + wave; rt < PRX / 16; rt += 3) {
-          if (min(NB / 16 - 1, rt) - cj1 == 2) syrk_row<2>(P, LDQ, jb, rt, cj1 + 1, lr, lq);
-          else syrk_row<1>(P, LDQ, jb, rt, cj1 + 1, lr, lq);
+          if (min(NB / 16 - 1, rt) - cj1 == 2) syrk_row<2>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq);
+          else syrk_row<1>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq);
         }
       }
       __syncthreads();
@@ -1312,6 +1315,161 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
 }
 
 // =================================================================================================
+// Cholesky solves with the inverted diagonal blocks (W = L11^-T, one 64 x 64 block per 64 pivots,
+// written by k_diag_chol): a block's triangular solve is a 64 x 64 matrix-vector product instead of
+// 64 dependent steps, and every load of a phase is issued before its first use.
+// One workgroup per front; r (LDS) holds the front's m entries: [0,n) pivots, [n,m) contribution rows.
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
+                 const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
+                 const double* __restrict__ L, const double* __restrict__ Linv,
+                 double* __restrict__ xp, double* __restrict__ cvec) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const NodeDesc nd = nodes[list[blockIdx.x]];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int n = nd.n, m = nd.m, cm = m - n;
+  double* r = sh;                         // m
+  double* part = sh + ((m + 63) & ~63);   // 4 x 64
+  const double* Lb = L + nd.loff;
+  const double* Wn = Linv + int64_t(nd.iblk) * (NB * NB);
+  STAMPN(8);
+  // X[row][k] = W[k + 64 row]: thread (row = lane, q) owns k in [16q, 16q+16) of the first block
+  double w[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) w[t] = Wn[64 * lane + 16 * q + t];
+  for (int i = tid; i < n; i += 256) r[i] = xp[nd.sptr + i];
+  for (int i = n + tid; i < m; i += 256) r[i] = 0.0;
+  __syncthreads();
+  for (int ci = nd.cbeg; ci < nd.cend; ++ci) {     // children's contribution vectors, one after the other
+    const NodeDesc cn = nodes[clist[ci]];
+    const int ccm = cn.m - cn.n;
+    const int32_t* map = cmap + cn.moff;
+    const double* cv = cvec + cn.moff;
+    for (int i = tid; i < ccm; i += 256) r[map[i]] += cv[i];
+    __syncthreads();
+  }
+  STAMPN(9);
+  for (int b = 0; b < n; b += 64) {
+    const int nb = min(64, n - b);
+    // rows below the block, first chunk: loads in flight while the block is solved
+    const int below = b + nb;
+    double l[64];
+    {
+      const int i = below + tid;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) l[k] = (i < m && k < nb) ? Lb[int64_t(b + k) * nd.ld + i] : 0.0;
+    }
+    // y_b = X_b r_b
+    {
+      double sacc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) sacc += w[t] * ((16 * q + t < nb) ? r[b + 16 * q + t] : 0.0);
+      part[q * 64 + lane] = sacc;
+    }
+    __syncthreads();
+    if (b + 64 < n) {   // next block's W
+      const double* W2 = Wn + int64_t((b >> 6) + 1) * (NB * NB);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) w[t] = W2[64 * lane + 16 * q + t];
+    }
+    if (tid < nb) r[b + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    __syncthreads();
+    // r[below ..) -= L[below.., b..b+nb) y_b : one row per thread
+    for (int c0 = below; c0 < m; c0 += 256) {
+      const int i = c0 + tid;
+      if (c0 > below) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) l[k] = (i < m && k < nb) ? Lb[int64_t(b + k) * nd.ld + i] : 0.0;
+      }
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) sacc += l[k] * r[b + (k < nb ? k : 0)];
+      if (i < m) r[i] -= sacc;
+    }
+    __syncthreads();
+  }
+  STAMPN(10);
+  for (int i = tid; i < n; i += 256) xp[nd.sptr + i] = r[i];
+  double* mine = cvec + nd.moff;
+  for (int i = tid; i < cm; i += 256) mine[i] = r[n + i];
+  STAMPN(11);
+}
+
+__global__ void __launch_bounds__(256)
+k_solve_bwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
+                 const int32_t* __restrict__ rlist, const double* __restrict__ L,
+                 const double* __restrict__ Linv, double* __restrict__ xp) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const NodeDesc nd = nodes[list[blockIdx.x]];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int n = nd.n, m = nd.m;
+  double* blk = sh;                        // 64 x SB tile of L, transposed access
+  double* part = sh + 64 * SB;             // 4 x 64
+  double* z = part + 256;                  // 64
+  double* r = z + 64;                      // m: [0,n) this front's pivots, [n,m) the ancestors' solution
+  const double* Lb = L + nd.loff;
+  const double* Wn = Linv + int64_t(nd.iblk) * (NB * NB);
+  const int32_t* rl = rlist + nd.roff;
+  STAMPN(16);
+  for (int i = tid; i < n; i += 256) r[i] = xp[nd.sptr + i];
+  for (int i = n + tid; i < m; i += 256) r[i] = xp[rl[i]];
+  for (int b = ((n - 1) >> 6) << 6; b >= 0; b -= 64) {
+    const int nb = min(64, n - b);
+    const int below = b + nb;
+    // (W z)[k] = sum_row W[k + 64 row] z[row]: thread (k = lane, q) owns rows [16q, 16q+16)
+    double w[16];
+    const double* Wb = Wn + int64_t(b >> 6) * (NB * NB);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = Wb[lane + 64 * (16 * q + t)];
+    // s[k] = sum_{i >= below} L[i, b+k] r[i]: 64-row tiles through LDS (coalesced along rows), thread
+    // (k, q) then walks 16 rows of column k; the next tile's loads are in flight meanwhile
+    double sacc = 0.0;
+    double v[16];
+    auto load_tile = [&](int i0) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = tid + 256 * t;
+        const int i = e & 63, k = e >> 6;
+        v[t] = (i0 + i < m && k < nb) ? Lb[int64_t(b + k) * nd.ld + i0 + i] : 0.0;
+      }
+    };
+    if (below < m) load_tile(below);
+    __syncthreads();                       // r complete (first pass) / previous block's r update visible
+    for (int i0 = below; i0 < m; i0 += 64) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = tid + 256 * t;
+        blk[(e >> 6) * SB + (e & 63)] = v[t];
+      }
+      __syncthreads();
+      if (i0 + 64 < m) load_tile(i0 + 64);
+      const int lim = min(16, m - i0 - 16 * q);
+#pragma unroll 4
+      for (int i = 0; i < lim; ++i) sacc += blk[lane * SB + 16 * q + i] * r[i0 + 16 * q + i];
+      __syncthreads();
+    }
+    part[q * 64 + lane] = sacc;
+    __syncthreads();
+    if (tid < 64) z[tid] = (tid < nb) ? r[b + tid] - ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) : 0.0;
+    __syncthreads();
+    {
+      double xacc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) xacc += w[t] * z[16 * q + t];
+      part[q * 64 + lane] = xacc;
+    }
+    __syncthreads();
+    if (tid < nb) r[b + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    // the next iteration's first barrier orders this write before any read of r
+  }
+  __syncthreads();
+  STAMPN(19);
+  for (int i = tid; i < n; i += 256) xp[nd.sptr + i] = r[i];
+  STAMPN(20);
+}
+
+// =================================================================================================
 // Solve path for BIG fronts (n > BIG_N or m > BIG_M): the front does not fit one workgroup's LDS and
 // one CU cannot stream it fast enough, so every 64-column block becomes two launches -- a 64 x 64
 // triangular solve (one workgroup per front) and a GEMV over the rows below it split into 256-row
@@ -1547,9 +1705,9 @@ static hipError_t allow_big_lds() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_chol), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   return hipSuccess;
 }
@@ -1863,10 +2021,16 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   if (do_fwd)
     for (int l = 0; l < S.nlevels; ++l) {
       const LevelPlan& lp = plan[l];
-      if (lp.small_cnt > 0)
-        hipLaunchKernelGGL(k_solve_fwd<POSDEF>, dim3(lp.small_cnt), dim3(256),
-                           sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
-                           F.smallnodes + lp.small_begin, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+      if (lp.small_cnt > 0) {
+        if (POSDEF)
+          hipLaunchKernelGGL(k_solve_fwd_chol, dim3(lp.small_cnt), dim3(256),
+                             sizeof(double) * (((lp.small_maxm + 63) & ~63) + 256), st, F.nodes,
+                             F.smallnodes + lp.small_begin, F.clist, F.cmap, F.L, F.Linv, xp, F.cvec);
+        else
+          hipLaunchKernelGGL(k_solve_fwd<false>, dim3(lp.small_cnt), dim3(256),
+                             sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
+                             F.smallnodes + lp.small_begin, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+      }
       if (lp.big_cnt > 0) {
         hipLaunchKernelGGL(k_big_fwd_prep<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
                            F.bignodes + lp.big_begin, F.clist, F.cmap, F.gperm, xp, F.cvec, F.ybuf);
@@ -1907,10 +2071,16 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
         hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
                            F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 0);
       }
-      if (lp.small_cnt > 0)
-        hipLaunchKernelGGL(k_solve_bwd<POSDEF>, dim3(lp.small_cnt), dim3(256),
-                           sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,
-                           F.smallnodes + lp.small_begin, F.rlist, F.gperm, F.L, xp);
+      if (lp.small_cnt > 0) {
+        if (POSDEF)
+          hipLaunchKernelGGL(k_solve_bwd_chol, dim3(lp.small_cnt), dim3(256),
+                             sizeof(double) * (64 * SB + 256 + 64 + std::max(lp.small_maxm, 1)), st, F.nodes,
+                             F.smallnodes + lp.small_begin, F.rlist, F.L, F.Linv, xp);
+        else
+          hipLaunchKernelGGL(k_solve_bwd<false>, dim3(lp.small_cnt), dim3(256),
+                             sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,
+                             F.smallnodes + lp.small_begin, F.rlist, F.gperm, F.L, xp);
+      }
     }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));
   return hipGetLastError();
