@@ -90,10 +90,13 @@ k_assemble(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ asmno
 // Tiled flavour for the first few children of every parent: one launch per child rank, so that the
 // children summed concurrently always belong to different parents (no atomics, fixed summation
 // order); a workgroup takes ACOLS columns of one child's contribution block.
-constexpr int ACOLS = 16;
+constexpr int ACOLS = 8;
 struct AsmTask {
   int32_t child, col0;
 };
+// A wave takes two columns of the child's block at a time; every load a phase needs (the maps and
+// the child's values, then the parent's entries) is issued before the first use, so a column costs
+// two memory round trips instead of one per 64 rows.
 __global__ void __launch_bounds__(256)
 k_assemble_tile(const NodeDesc* __restrict__ nodes, const AsmTask* __restrict__ tasks,
                 const int32_t* __restrict__ cmap, double* __restrict__ L, double* __restrict__ C) {
@@ -104,20 +107,47 @@ k_assemble_tile(const NodeDesc* __restrict__ nodes, const AsmTask* __restrict__ 
   const int cm = Cn.m - Cn.n, pcm = P.m - P.n;
   const int32_t* map = cmap + Cn.moff;
   const double* src = C + Cn.coff;
-  const int jend = min(t.col0 + ACOLS, cm);
-  for (int j = t.col0 + wave; j < jend; j += 4) {
-    const int pc = map[j];
-    double* dst = (pc < P.n) ? (L + P.loff + int64_t(pc) * P.ld)
-                             : (C + P.coff + int64_t(pc - P.n) * pcm - P.n);
-    const double* sc = src + int64_t(j) * cm;
-    int i = j + lane;
-    for (; i + 192 < cm; i += 256) {   // four independent read-modify-writes in flight per lane
-      const int m0 = map[i], m1 = map[i + 64], m2 = map[i + 128], m3 = map[i + 192];
-      const double v0 = sc[i], v1 = sc[i + 64], v2 = sc[i + 128], v3 = sc[i + 192];
-      const double d0 = dst[m0], d1 = dst[m1], d2 = dst[m2], d3 = dst[m3];
-      dst[m0] = d0 + v0; dst[m1] = d1 + v1; dst[m2] = d2 + v2; dst[m3] = d3 + v3;
+  constexpr int U = 4;   // 256 rows per pass
+  const int j0 = t.col0 + 2 * wave;
+  for (int base = 0; base < cm; base += 64 * U) {
+    int mi[U];
+    double v[2][U];
+    int pc[2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + lane + 64 * u;
+      mi[u] = (i < cm) ? map[i] : 0;
     }
-    for (; i < cm; i += 64) dst[map[i]] += sc[i];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = j0 + c;
+      pc[c] = (j < cm) ? map[j] : 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + lane + 64 * u;
+        v[c][u] = (j < cm && i >= j && i < cm) ? src[int64_t(j) * cm + i] : 0.0;
+      }
+    }
+    double* dst[2];
+    double d[2][U];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      dst[c] = (pc[c] < P.n) ? (L + P.loff + int64_t(pc[c]) * P.ld)
+                             : (C + P.coff + int64_t(pc[c] - P.n) * pcm - P.n);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + lane + 64 * u;
+        const bool ok = (j0 + c < cm && i >= j0 + c && i < cm);
+        d[c][u] = ok ? dst[c][mi[u]] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + lane + 64 * u;
+        if (j0 + c < cm && i >= j0 + c && i < cm) dst[c][mi[u]] = d[c][u] + v[c][u];
+      }
   }
 }
 
@@ -992,7 +1022,7 @@ k_panel_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ t
 // contribution kernel: tile (ti,tj) of  C -= L21 * D * L21^T   (K = n, MFMA)
 // =================================================================================================
 template <bool POSDEF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks,
           const double* __restrict__ L, const double* __restrict__ D, double* __restrict__ C) {
   __shared__ Stage<TS, CK> sg;
