@@ -18,6 +18,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "gsls_device.hpp"
 
@@ -59,95 +60,74 @@ __global__ void k_scatter_a(int64_t cnt, const int64_t* __restrict__ asrc,
 
 // =================================================================================================
 // extend-add: every parent pulls its children's contribution blocks, one child after the other
-// (deterministic summation order, no atomics).  One workgroup per parent.
+// (deterministic summation order, no atomics).
 // =================================================================================================
-__global__ void __launch_bounds__(256)
-k_assemble(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ asmnodes,
-           const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
-           double* __restrict__ L, double* __restrict__ C, int first_rank) {
-  const int p = asmnodes[blockIdx.x];
-  const NodeDesc P = nodes[p];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pcm = P.m - P.n;
-  for (int ci = P.cbeg + first_rank; ci < P.cend; ++ci) {
-    const NodeDesc Cn = nodes[clist[ci]];
-    const int cm = Cn.m - Cn.n;
-    if (cm > 0) {
-      const int32_t* map = cmap + Cn.moff;
-      const double* src = C + Cn.coff;
-      for (int j = wave; j < cm; j += 4) {
-        const int pc = map[j];
-        double* dst = (pc < P.n) ? (L + P.loff + int64_t(pc) * P.ld)
-                                 : (C + P.coff + int64_t(pc - P.n) * pcm - P.n);
-        const double* s = src + int64_t(j) * cm;
-        for (int i = j + lane; i < cm; i += 64) dst[map[i]] += s[i];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// Tiled flavour for the first few children of every parent: one launch per child rank, so that the
-// children summed concurrently always belong to different parents (no atomics, fixed summation
-// order); a workgroup takes ACOLS columns of one child's contribution block.
-constexpr int ACOLS = 8;
-struct AsmTask {
-  int32_t child, col0;
+// Pull flavour, one launch per level: a workgroup owns PCOLS columns of a parent front and walks the
+// children IN ORDER, adding from each the (host-computed) range of its columns that land there --
+// deterministic summation order without atomics and without one launch per child rank.
+constexpr int PCOLS = 8;
+struct PullSeg {       // columns [j0, j1) of one child's contribution block, with everything the adds need
+  int32_t j0, j1, cm, pn, pld, ppcm;
+  int64_t cmoff, ccoff, ploff, pcoff;
 };
-// A wave takes two columns of the child's block at a time; every load a phase needs (the maps and
-// the child's values, then the parent's entries) is issued before the first use, so a column costs
-// two memory round trips instead of one per 64 rows.
+struct PullTask {
+  int32_t seg_begin, seg_cnt;
+};
 __global__ void __launch_bounds__(256)
-k_assemble_tile(const NodeDesc* __restrict__ nodes, const AsmTask* __restrict__ tasks,
+k_assemble_pull(const PullTask* __restrict__ tasks, const PullSeg* __restrict__ segs,
                 const int32_t* __restrict__ cmap, double* __restrict__ L, double* __restrict__ C) {
-  const AsmTask t = tasks[blockIdx.x];
-  const NodeDesc Cn = nodes[t.child];
-  const NodeDesc P = nodes[Cn.parent];
+  const PullTask t = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cm = Cn.m - Cn.n, pcm = P.m - P.n;
-  const int32_t* map = cmap + Cn.moff;
-  const double* src = C + Cn.coff;
   constexpr int U = 4;   // 256 rows per pass
-  const int j0 = t.col0 + 2 * wave;
-  for (int base = 0; base < cm; base += 64 * U) {
-    int mi[U];
-    double v[2][U];
-    int pc[2];
+  for (int si = 0; si < t.seg_cnt; ++si) {
+    const PullSeg sg = segs[t.seg_begin + si];
+    const int cm = sg.cm;
+    const int32_t* map = cmap + sg.cmoff;
+    const double* src = C + sg.ccoff;
+    const int j0 = sg.j0 + 2 * wave;
+    if (j0 < sg.j1) {
+      const int nc = min(2, sg.j1 - j0);
+      for (int base = (j0 / (64 * U)) * (64 * U); base < cm; base += 64 * U) {
+        int mi[U];
+        double v[2][U];
+        int pc[2];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + lane + 64 * u;
-      mi[u] = (i < cm) ? map[i] : 0;
-    }
+        for (int u = 0; u < U; ++u) {
+          const int i = base + lane + 64 * u;
+          mi[u] = (i < cm) ? map[i] : 0;
+        }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int j = j0 + c;
-      pc[c] = (j < cm) ? map[j] : 0;
+        for (int c = 0; c < 2; ++c) {
+          const int j = j0 + c;
+          pc[c] = (c < nc) ? map[j] : 0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = base + lane + 64 * u;
-        v[c][u] = (j < cm && i >= j && i < cm) ? src[int64_t(j) * cm + i] : 0.0;
+          for (int u = 0; u < U; ++u) {
+            const int i = base + lane + 64 * u;
+            v[c][u] = (c < nc && i >= j && i < cm) ? src[int64_t(j) * cm + i] : 0.0;
+          }
+        }
+        double* dst[2];
+        double d[2][U];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          dst[c] = (pc[c] < sg.pn) ? (L + sg.ploff + int64_t(pc[c]) * sg.pld)
+                                   : (C + sg.pcoff + int64_t(pc[c] - sg.pn) * sg.ppcm - sg.pn);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int i = base + lane + 64 * u;
+            d[c][u] = (c < nc && i >= j0 + c && i < cm) ? dst[c][mi[u]] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int i = base + lane + 64 * u;
+            if (c < nc && i >= j0 + c && i < cm) dst[c][mi[u]] = d[c][u] + v[c][u];
+          }
       }
     }
-    double* dst[2];
-    double d[2][U];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      dst[c] = (pc[c] < P.n) ? (L + P.loff + int64_t(pc[c]) * P.ld)
-                             : (C + P.coff + int64_t(pc[c] - P.n) * pcm - P.n);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = base + lane + 64 * u;
-        const bool ok = (j0 + c < cm && i >= j0 + c && i < cm);
-        d[c][u] = ok ? dst[c][mi[u]] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = base + lane + 64 * u;
-        if (j0 + c < cm && i >= j0 + c && i < cm) dst[c][mi[u]] = d[c][u] + v[c][u];
-      }
+    __syncthreads();   // the next child may add to the same entries
   }
 }
 
@@ -473,9 +453,11 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   }
   STAMP(16);
   // ---- store L (lower trapezoid) and W = L11^-T; both coalesced along rows ---------------------------
-  for (int e = tid; e < pr * w; e += 256) {
-    const int row = e % pr, col = e / pr;
-    if (row >= col) Lb[int64_t(kb + col) * nd.ld + kb + row] = P[col * LDQ + row];
+  {
+    const int row = tid & (PR - 1);
+    double* dst = Lb + int64_t(kb) * nd.ld + kb + row;
+    for (int col = tid >> 7; col < w; col += 2)
+      if (row >= col && row < pr) dst[int64_t(col) * nd.ld] = P[col * LDQ + row];
   }
   double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
   for (int e = tid; e < NB * NB; e += 256) W[e] = P[(e >> 6) * LDQ + PR + (e & 63)];
@@ -1350,13 +1332,29 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
 // 64 dependent steps, and every load of a phase is issued before its first use.
 // One workgroup per front; r (LDS) holds the front's m entries: [0,n) pivots, [n,m) contribution rows.
 // =================================================================================================
+// Everything a solve workgroup needs to know about its front in ONE load (no list -> node -> child
+// pointer chase at the head of every launch): the front, and its first two children's vectors.
+struct SolveTask {
+  int32_t m, n, ld, sptr;
+  int64_t loff, roff, moff;
+  int32_t iblk, cbeg, cend, ccm0, ccm1, pad;
+  int64_t cmoff0, cmoff1;
+};
+
+// rows [i] x columns [b, b+nb) of a front, one row per thread, every load issued before any use
+__device__ __forceinline__ void load_row64(double (&l)[64], const double* __restrict__ Lb, int ld, int b,
+                                           int nb, int i, int m) {
+#pragma unroll
+  for (int k = 0; k < 64; ++k) l[k] = (i < m && k < nb) ? Lb[int64_t(b + k) * ld + i] : 0.0;
+}
+
 __global__ void __launch_bounds__(256)
-k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
+k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const SolveTask* __restrict__ tasks,
                  const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
                  const double* __restrict__ L, const double* __restrict__ Linv,
                  double* __restrict__ xp, double* __restrict__ cvec) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const NodeDesc nd = nodes[list[blockIdx.x]];
+  const SolveTask nd = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const int n = nd.n, m = nd.m, cm = m - n;
   double* r = sh;                         // m
@@ -1364,14 +1362,39 @@ k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__
   const double* Lb = L + nd.loff;
   const double* Wn = Linv + int64_t(nd.iblk) * (NB * NB);
   STAMPN(8);
-  // X[row][k] = W[k + 64 row]: thread (row = lane, q) owns k in [16q, 16q+16) of the first block
+  // ---- everything that depends on nothing goes out first: W of block 0, the first 256 rows below
+  // blocks 0 and 1, the right-hand side, the first two children's contribution vectors
+  // X[row][k] = W[k + 64 row]: thread (row = lane, q) owns k in [16q, 16q+16)
   double w[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) w[t] = Wn[64 * lane + 16 * q + t];
+  const int nb0 = min(64, n);
+  double la[64];
+  load_row64(la, Lb, nd.ld, 0, nb0, nb0 + tid, m);
+  const int nchild = nd.cend - nd.cbeg;
+  const int ccm2[2] = {nd.ccm0, nd.ccm1};
+  const int64_t moff2[2] = {nd.cmoff0, nd.cmoff1};
+  int mi2[2] = {0, 0};
+  double cv2[2] = {0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (c < nchild && tid < ccm2[c]) {
+      mi2[c] = cmap[moff2[c] + tid];
+      cv2[c] = cvec[moff2[c] + tid];
+    }
   for (int i = tid; i < n; i += 256) r[i] = xp[nd.sptr + i];
   for (int i = n + tid; i < m; i += 256) r[i] = 0.0;
   __syncthreads();
-  for (int ci = nd.cbeg; ci < nd.cend; ++ci) {     // children's contribution vectors, one after the other
+  STAMPN(23);
+  // children's contribution vectors, one child after the other (fixed summation order)
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (c < nchild) {
+      if (tid < ccm2[c]) r[mi2[c]] += cv2[c];
+      for (int i = tid + 256; i < ccm2[c]; i += 256) r[cmap[moff2[c] + i]] += cvec[moff2[c] + i];
+      __syncthreads();
+    }
+  for (int ci = nd.cbeg + 2; ci < nd.cend; ++ci) {
     const NodeDesc cn = nodes[clist[ci]];
     const int ccm = cn.m - cn.n;
     const int32_t* map = cmap + cn.moff;
@@ -1380,16 +1403,15 @@ k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__
     __syncthreads();
   }
   STAMPN(9);
+  auto apply = [&](const double (&l)[64], int b, int nb, int i) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) sacc += l[k] * r[b + (k < nb ? k : 0)];
+    if (i < m) r[i] -= sacc;
+  };
   for (int b = 0; b < n; b += 64) {
     const int nb = min(64, n - b);
-    // rows below the block, first chunk: loads in flight while the block is solved
     const int below = b + nb;
-    double l[64];
-    {
-      const int i = below + tid;
-#pragma unroll
-      for (int k = 0; k < 64; ++k) l[k] = (i < m && k < nb) ? Lb[int64_t(b + k) * nd.ld + i] : 0.0;
-    }
     // y_b = X_b r_b
     {
       double sacc = 0.0;
@@ -1398,6 +1420,7 @@ k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__
       part[q * 64 + lane] = sacc;
     }
     __syncthreads();
+    STAMPN(24 + 4 * (b >> 6));
     if (b + 64 < n) {   // next block's W
       const double* W2 = Wn + int64_t((b >> 6) + 1) * (NB * NB);
 #pragma unroll
@@ -1405,19 +1428,17 @@ k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__
     }
     if (tid < nb) r[b + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
     __syncthreads();
-    // r[below ..) -= L[below.., b..b+nb) y_b : one row per thread
+    STAMPN(25 + 4 * (b >> 6));
+    // r[below ..) -= L[below.., b..b+nb) y_b : one row per thread, 256 rows per pass
     for (int c0 = below; c0 < m; c0 += 256) {
       const int i = c0 + tid;
-      if (c0 > below) {
-#pragma unroll
-        for (int k = 0; k < 64; ++k) l[k] = (i < m && k < nb) ? Lb[int64_t(b + k) * nd.ld + i] : 0.0;
-      }
-      double sacc = 0.0;
-#pragma unroll
-      for (int k = 0; k < 64; ++k) sacc += l[k] * r[b + (k < nb ? k : 0)];
-      if (i < m) r[i] -= sacc;
+      if (c0 > below) load_row64(la, Lb, nd.ld, b, nb, i, m);
+      apply(la, b, nb, i);
     }
     __syncthreads();
+    STAMPN(26 + 4 * (b >> 6));
+    // first 256 rows below the next block: in flight while that block is solved
+    if (b + 64 < n) load_row64(la, Lb, nd.ld, b + 64, min(64, n - b - 64), b + 64 + min(64, n - b - 64) + tid, m);
   }
   STAMPN(10);
   for (int i = tid; i < n; i += 256) xp[nd.sptr + i] = r[i];
@@ -1427,11 +1448,10 @@ k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-k_solve_bwd_chol(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
-                 const int32_t* __restrict__ rlist, const double* __restrict__ L,
-                 const double* __restrict__ Linv, double* __restrict__ xp) {
+k_solve_bwd_chol(const SolveTask* __restrict__ tasks, const int32_t* __restrict__ rlist,
+                 const double* __restrict__ L, const double* __restrict__ Linv, double* __restrict__ xp) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const NodeDesc nd = nodes[list[blockIdx.x]];
+  const SolveTask nd = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const int n = nd.n, m = nd.m;
   double* blk = sh;                        // 64 x SB tile of L, transposed access
@@ -1720,10 +1740,10 @@ extern "C" void gsls_debug_stamps(unsigned long long* out) {
 #endif
 
 void dev_free(DeviceFactor& F) {
-  void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.asmnodes, F.asrc, F.adst, F.arow,
+  void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
-                  F.xhost, F.stat, F.gperm, F.asmtasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.Linv, F.segC, F.segV, F.posowner};
+                  F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.segC, F.segV, F.posowner};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -1784,8 +1804,8 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   // launch plan
   std::vector<PanelTask> pt;
   std::vector<TileTask> tt;
-  std::vector<int32_t> asmn;
-  std::vector<AsmTask> at;
+  std::vector<PullSeg> psg;
+  std::vector<PullTask> ptk;
   std::vector<int32_t> smalln, bign;
   std::vector<BigTrsv> btr;
   std::vector<BigGemv> bgm;
@@ -1833,24 +1853,28 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         for (int ti = tj; ti < nt; ++ti) tt.push_back(TileTask{s, ti, tj, 0});
     }
     lp.tile_cnt = int(tt.size()) - lp.tile_begin;
-    // extend-add: child ranks 0..ASM_RANKS-1 as tiled launches, the rest one workgroup per parent
-    for (int rk = 0; rk < ASM_RANKS; ++rk) {
-      lp.asmt_begin[rk] = int(at.size());
-      for (int i = lp.node_begin; i < lp.node_end; ++i) {
-        const int s = lvl_nodes[i];
-        if (S.cptr[s] + rk >= S.cptr[s + 1]) continue;
-        const int c = S.clist[S.cptr[s] + rk];
-        const int cm = S.nrow(c) - S.ncol(c);
-        for (int c0 = 0; c0 < cm; c0 += ACOLS) at.push_back(AsmTask{c, c0});
-      }
-      lp.asmt_cnt[rk] = int(at.size()) - lp.asmt_begin[rk];
-    }
-    lp.asm_begin = int(asmn.size());
+    // extend-add: one pull task per PCOLS columns of every parent, children in clist order
+    lp.pull_begin = int(ptk.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
       const int s = lvl_nodes[i];
-      if (S.cptr[s + 1] - S.cptr[s] > ASM_RANKS) asmn.push_back(s);
+      if (S.cptr[s + 1] == S.cptr[s]) continue;
+      const int pm = S.nrow(s), pn = S.ncol(s);
+      for (int pc0 = 0; pc0 < pm; pc0 += PCOLS) {
+        PullTask tk{int(psg.size()), 0};
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
+          const int c = S.clist[ci];
+          const int cmc = S.nrow(c) - S.ncol(c);
+          const int32_t* mp = S.cmap.data() + S.cmapptr[c];
+          const int j0 = int(std::lower_bound(mp, mp + cmc, pc0) - mp);
+          const int j1 = int(std::lower_bound(mp, mp + cmc, pc0 + PCOLS) - mp);
+          if (j1 > j0)
+            psg.push_back(PullSeg{j0, j1, cmc, pn, S.ldl[s], pm - pn, S.cmapptr[c], S.coff[c], S.loff[s], S.coff[s]});
+        }
+        tk.seg_cnt = int(psg.size()) - tk.seg_begin;
+        if (tk.seg_cnt > 0) ptk.push_back(tk);
+      }
     }
-    lp.asm_cnt = int(asmn.size()) - lp.asm_begin;
+    lp.pull_cnt = int(ptk.size()) - lp.pull_begin;
     // solve: small fronts (one workgroup each) and big fronts (blocked multi-launch path)
     lp.small_begin = int(smalln.size());
     lp.big_begin = int(bign.size());
@@ -1904,8 +1928,39 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(upload(F.cmap, S.cmap, st));
   HIPCHK(upload(F.clist, S.clist, st));
   HIPCHK(upload(F.lvlnodes, S.lvlnodes, st));
-  HIPCHK(upload(F.asmnodes, asmn, st));
   HIPCHK(upload(F.smallnodes, smalln, st));
+  {
+    std::vector<SolveTask> stv(smalln.size());
+    for (size_t i = 0; i < smalln.size(); ++i) {
+      const int sn = smalln[i];
+      SolveTask& t = stv[i];
+      t.m = S.nrow(sn);
+      t.n = S.ncol(sn);
+      t.ld = S.ldl[sn];
+      t.sptr = S.sptr[sn];
+      t.loff = S.loff[sn];
+      t.roff = S.rptr[sn];
+      t.moff = S.cmapptr[sn];
+      t.iblk = nd[sn].iblk;
+      t.cbeg = S.cptr[sn];
+      t.cend = S.cptr[sn + 1];
+      t.ccm0 = t.ccm1 = t.pad = 0;
+      t.cmoff0 = t.cmoff1 = 0;
+      if (t.cend - t.cbeg > 0) {
+        const int c = S.clist[t.cbeg];
+        t.ccm0 = S.nrow(c) - S.ncol(c);
+        t.cmoff0 = S.cmapptr[c];
+      }
+      if (t.cend - t.cbeg > 1) {
+        const int c = S.clist[t.cbeg + 1];
+        t.ccm1 = S.nrow(c) - S.ncol(c);
+        t.cmoff1 = S.cmapptr[c];
+      }
+    }
+    SolveTask* d = nullptr;
+    HIPCHK(upload(d, stv, st));
+    F.stasks = d;
+  }
   HIPCHK(upload(F.bignodes, bign, st));
   {
     BigTrsv* d1 = nullptr;
@@ -1941,9 +1996,12 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.ybuf), std::max(S.n, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.part), std::max<int64_t>(part_max, 1) * 64 * sizeof(double)));
   {
-    AsmTask* d = nullptr;
-    HIPCHK(upload(d, at, st));
-    F.asmtasks = d;
+    PullSeg* d1 = nullptr;
+    PullTask* d2 = nullptr;
+    HIPCHK(upload(d1, psg, st));
+    HIPCHK(upload(d2, ptk, st));
+    F.pullsegs = d1;
+    F.pulltasks = d2;
   }
   HIPCHK(upload(F.asrc, asrc, st));
   HIPCHK(upload(F.adst, adst, st));
@@ -1978,13 +2036,10 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
   const size_t lds_pchol = std::max(sizeof(Stage<RB, CK>), sizeof(double) * (2 * NB * RBP));
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
-    for (int rk = 0; rk < ASM_RANKS; ++rk)
-      if (lp.asmt_cnt[rk] > 0)
-        hipLaunchKernelGGL(k_assemble_tile, dim3(lp.asmt_cnt[rk]), dim3(256), 0, st, F.nodes,
-                           static_cast<const AsmTask*>(F.asmtasks) + lp.asmt_begin[rk], F.cmap, F.L, F.C);
-    if (lp.asm_cnt > 0)
-      hipLaunchKernelGGL(k_assemble, dim3(lp.asm_cnt), dim3(256), 0, st, F.nodes,
-                         F.asmnodes + lp.asm_begin, F.clist, F.cmap, F.L, F.C, ASM_RANKS);
+    if (lp.pull_cnt > 0)
+      hipLaunchKernelGGL(k_assemble_pull, dim3(lp.pull_cnt), dim3(256), 0, st,
+                         static_cast<const PullTask*>(F.pulltasks) + lp.pull_begin,
+                         static_cast<const PullSeg*>(F.pullsegs), F.cmap, F.L, F.C);
     const int nsteps = int(lp.panel_cnt.size() / 2);
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
@@ -2055,7 +2110,8 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
         if (POSDEF)
           hipLaunchKernelGGL(k_solve_fwd_chol, dim3(lp.small_cnt), dim3(256),
                              sizeof(double) * (((lp.small_maxm + 63) & ~63) + 256), st, F.nodes,
-                             F.smallnodes + lp.small_begin, F.clist, F.cmap, F.L, F.Linv, xp, F.cvec);
+                             static_cast<const SolveTask*>(F.stasks) + lp.small_begin, F.clist, F.cmap, F.L, F.Linv,
+                             xp, F.cvec);
         else
           hipLaunchKernelGGL(k_solve_fwd<false>, dim3(lp.small_cnt), dim3(256),
                              sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
@@ -2104,8 +2160,8 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
       if (lp.small_cnt > 0) {
         if (POSDEF)
           hipLaunchKernelGGL(k_solve_bwd_chol, dim3(lp.small_cnt), dim3(256),
-                             sizeof(double) * (64 * SB + 256 + 64 + std::max(lp.small_maxm, 1)), st, F.nodes,
-                             F.smallnodes + lp.small_begin, F.rlist, F.L, F.Linv, xp);
+                             sizeof(double) * (64 * SB + 256 + 64 + std::max(lp.small_maxm, 1)), st,
+                             static_cast<const SolveTask*>(F.stasks) + lp.small_begin, F.rlist, F.L, F.Linv, xp);
         else
           hipLaunchKernelGGL(k_solve_bwd<false>, dim3(lp.small_cnt), dim3(256),
                              sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,

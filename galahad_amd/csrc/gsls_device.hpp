@@ -15,7 +15,6 @@ constexpr int TS = 64;   // contribution-block tile edge
 constexpr int BIG_N = 256;    // fronts wider / taller than this use the blocked multi-launch solve
 constexpr int BIG_M = 4096;
 constexpr int FAILCAP = 16384;  // capacity of the failed-pivot report of one factorization pass
-constexpr int ASM_RANKS = 4;  // children of a parent assembled by tiled launches (one per rank)
 
 // One front.  L block: m x n column-major, leading dimension ld, at L + loff.
 // Contribution block: (m-n) x (m-n) column-major (lower triangle meaningful) at C + coff.
@@ -45,8 +44,7 @@ struct LevelPlan {
   int node_begin, node_end;                 // range in lvlnodes
   std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
   int tile_begin, tile_cnt;                 // range in the TileTask array
-  int asm_begin, asm_cnt;                   // parents with > ASM_RANKS children: range in asm node list
-  int asmt_begin[ASM_RANKS], asmt_cnt[ASM_RANKS];   // tiled extend-add tasks per child rank
+  int pull_begin, pull_cnt;                 // extend-add tasks of the level (k_assemble_pull)
   int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
   int big_begin, big_cnt;                                // solve: blocked multi-launch fronts
   std::vector<BigStep> bigsteps;
@@ -59,9 +57,10 @@ struct DeviceFactor {
   int32_t* cmap = nullptr;
   int32_t* clist = nullptr;
   int32_t* lvlnodes = nullptr;
-  int32_t* asmnodes = nullptr;
-  void* asmtasks = nullptr;
+  void* pullsegs = nullptr;        // extend-add: PullSeg / PullTask lists (gsls_device.hip)
+  void* pulltasks = nullptr;
   int32_t* smallnodes = nullptr;
+  void* stasks = nullptr;          // SolveTask per entry of smallnodes (same indexing)
   int32_t* bignodes = nullptr;
   void* bigtrsv = nullptr;
   void* biggemv = nullptr;

@@ -12,6 +12,8 @@ s.analyse(m,ct,i); s.factorize(m,ct,i)
 for rep in range(2):
     x=s.solve(m,rhs,ct,i)
     st=(C.c_ulonglong*64)(); raw.gsls_debug_stamps(st)
-    v=[st[k] for k in range(32)]
-    print('fwd: gather %d  trsv-blocks %d  store %d  gemv %d | bwd: load %d gemvT %d trsv %d store %d'%(v[9]-v[8],v[10]-v[9],0,v[11]-v[10], v[17]-v[16], v[18]-v[17], v[19]-v[18], v[20]-v[19]))
+    v=[st[k] for k in range(40)]
+    d=lambda a,b:v[b]-v[a]
+    print('fwd cycles: init %d children %d | blk0: matvec %d y %d upd %d | blk1: matvec %d y %d upd %d | store %d | total %d'%(d(8,23),d(23,9),d(9,24),d(24,25),d(25,26),d(26,28),d(28,29),d(29,30),d(10,11),d(8,11)))
+    print('bwd cycles: total %d'%(d(16,20)))
 print(np.abs(x-xs).max())
