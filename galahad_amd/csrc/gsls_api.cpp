@@ -11,6 +11,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -25,6 +26,7 @@ struct Handle {
   Symbolic S;
   DeviceFactor F;
   bool analysed = false, factored = false, posdef = false, dev_ready = false, have_scale = false;
+  bool learned = false;       // the in-block pivot sequence of a pivoted factorization has been folded into the order
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -195,7 +197,7 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
     options = &defo;
   }
   const double t0 = now();
-  h->analysed = h->factored = h->dev_ready = false;
+  h->analysed = h->factored = h->dev_ready = h->learned = false;
   if (n < 0) return inform->flag = GSLS_ERROR_A_N_OOR;
   if (n > 0 && (!ptr || !row)) return inform->flag = GSLS_ERROR_A_PTR;
   if (n > 0 && ptr[0] != 1) return inform->flag = GSLS_ERROR_A_PTR;
@@ -305,6 +307,49 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     if (e != hipSuccess) return fail_hip(h, inform, e);
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
+    if (getenv("GSLS_DEBUG"))
+      fprintf(stderr, "[gsls] pass %d: blocks fast %d, pivoted %d, failed columns %d, 2x2 %d\n", pass, st[6], st[7], st[4], st[3]);
+    if (!posdef && st[4] == 0 && !h->learned && st[7] > 0) {
+      // ---- learn: fold the pivot sequence the complete-pivoting kernel chose inside its blocks into the
+      // elimination order, and remember where it took 2x2 pivots, so that later factorizations of
+      // this pattern (the next interior-point iterations) go through the optimistic kernel
+      h->learned = true;
+      const int n = h->S.n;
+      std::vector<int32_t> gp(n);
+      std::vector<double> Dh(2 * size_t(n) + 4);
+      e = hipMemcpy(gp.data(), F.gperm, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      e = hipMemcpy(Dh.data(), F.D, Dh.size() * sizeof(double), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      std::vector<uint8_t> hints(n, 0);
+      bool moved = false, any2 = false;
+      std::vector<int32_t> order(n);
+      for (int i = 0; i < n; ++i) {
+        order[h->S.invp[gp[i]]] = i + 1;
+        moved |= (gp[i] != i);
+        if (i + 1 < n && std::isinf(Dh[2 * size_t(i) + 2])) { hints[i] = 1; any2 = true; }
+      }
+      if (moved) {
+        int flag2;
+        try {
+          flag2 = symbolic_analyse(n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S);
+        } catch (const std::bad_alloc&) {
+          return inform->flag = GSLS_ERROR_ALLOCATION;
+        }
+        if (flag2 < 0) return inform->flag = flag2;
+        fill_from_symbolic(h->S, inform);
+        inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+        e = dev_upload_symbolic(h->S, F, h->stream);
+        if (e != hipSuccess) return fail_hip(h, inform, e);
+        e = stage_inputs();
+        if (e != hipSuccess) return fail_hip(h, inform, e);
+      }
+      if (moved || any2) {
+        e = hipMemcpy(F.hint, hints.data(), size_t(n), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail_hip(h, inform, e);
+      }
+      if (moved) continue;     // factorize once more in the learned order
+    }
     if (posdef || st[4] == 0) break;
     // ---- some pivots failed: repair the elimination order and go again ---------------------------
     const int nf = std::min<int>(st[5], FAILCAP);
@@ -322,6 +367,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       return inform->flag;
     }
     total_moved += int(failed.size());
+    h->learned = false;   // the order changes: learn the in-block pivot sequence again afterwards
     int flag2;
     try {
       flag2 = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER,
@@ -728,6 +774,15 @@ int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rp
   if (rlist) for (int64_t i = 0; i < S.rptr[nn]; ++i) rlist[i] = S.rlist[i] + 1;
   if (nptr) for (int i = 0; i <= nn; ++i) nptr[i] = S.nptr[i] + 1;
   if (nlist) for (int64_t i = 0; i < 2 * S.nptr[nn]; ++i) nlist[i] = S.nlist[i] + 1;
+  return GSLS_SUCCESS;
+}
+
+// order[var] = 1-based pivot position in the elimination order currently held by the handle (the one
+// given to / computed by analyse, as repaired by later factorizations)
+int gsls_get_order(void* handle, int32_t* order) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !order) return GSLS_ERROR_CALL_SEQUENCE;
+  for (int i = 0; i < h->S.n; ++i) order[i] = h->S.perm[i] + 1;
   return GSLS_SUCCESS;
 }
 

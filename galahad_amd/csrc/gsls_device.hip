@@ -271,18 +271,22 @@ constexpr int LDQ = PRX + 16;    // == 16 mod 32 doubles: conflict-free MFMA ope
 
 // P[row tile rt, col tiles cj0 .. cj0+NC) -= Y[rt] Y[cj]^T with Y = columns jb..jb+16 of the LDS panel
 template <int NC>
-__device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int cj0, int w, int lr, int lq) {
+__device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int cj0, int w, int lr, int lq,
+                                         const double* ypb = nullptr) {   // ypb: Y' = R L^-T (LDL^T), [16][ldq]
   const int row0 = 16 * rt;
   double yb[4], ya[NC][4];
   double4_t c[NC];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) yb[k] = P[(jb + 4 * k + lq) * ldq + row0 + lr];
+  for (int k = 0; k < 4; ++k)
+    yb[k] = ypb ? ypb[(4 * k + lq) * ldq + row0 + lr] : P[(jb + 4 * k + lq) * ldq + row0 + lr];
 #pragma unroll
   for (int q = 0; q < NC; ++q) {
     const int col0 = 16 * (cj0 + q);
 #pragma unroll
     // columns >= w are padding (unit diagonal): they must not see the real rows' updates
-    for (int k = 0; k < 4; ++k) ya[q][k] = (col0 + lr < w) ? -P[(jb + 4 * k + lq) * ldq + col0 + lr] : 0.0;
+    for (int k = 0; k < 4; ++k) {
+      ya[q][k] = (col0 + lr < w) ? -P[(jb + 4 * k + lq) * ldq + col0 + lr] : 0.0;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) c[q][r] = P[(col0 + lq + 4 * r) * ldq + row0 + lr];
   }
@@ -298,13 +302,26 @@ __device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int
   }
 }
 
+// LDL = true: the same pipeline as an OPTIMISTIC pass of the pivoted LDL^T -- pivots taken in the given
+// order, 1x1 only, every multiplier checked against 1/u and every pivot against `small`.  If a check
+// fails anywhere in the block nothing is stored and fastok[block] = 0: k_diag_ldlt (complete pivoting,
+// 2x2 pivots) then redoes that block; blocks that pass are skipped by it.  (Optimistic first, robust
+// fallback: the a-posteriori idea of ldlt_app.cxx:303-321 at block granularity.)
+template <bool LDL>
 __global__ void __launch_bounds__(256)
-k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
-            double* __restrict__ L, double* __restrict__ Linv, int32_t* __restrict__ stat) {
+k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
+            double* __restrict__ L, double* __restrict__ Linv, double* __restrict__ D,
+            int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
+            double small, double u) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR, CK>& sg = *reinterpret_cast<Stage<PR, CK>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);  // [NB][LDQ], overlays the staging buffers after the GEMM
+  double* YP = P + NB * LDQ;                        // LDL: [16][LDQ], Y' = R L16^-T of the current stage
   __shared__ double Xs[16 * 16];                    // Xs[k][n] = (L16^-1)[n][k]
+  __shared__ double Zs[16 * 16];                    // LDL: Zs[k][n] = (D16^-1 L16^-1)[n][k]
+  __shared__ double dgs[2 * NB + 4];                // LDL: inverted pivots in the layout of D
+  __shared__ int32_t s_neg, s_two;
+  constexpr int NRT = (LDL ? PR : PRX) / 16;        // row tiles: the identity rows (W) only for Cholesky
 
   const PanelTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
@@ -314,6 +331,9 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   const int w = min(NB, nd.n - kb);
   const int pr = min(PR, nd.m - kb);
   double* Lb = L + nd.loff;
+  const double* dinv = LDL ? (D + 2 * int64_t(nd.sptr)) : nullptr;
+  const double inv_u = (LDL && u > 0.0) ? 1.0 / u : INFINITY;
+  bool bad = false;
 
   STAMP(0);
   // the block's own entries first: their latency hides behind the left-looking update.  Tiles are
@@ -337,12 +357,12 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
   if (kb > 0) {
     StageRegs<PR, CK> rg;
-    stage_load<PR, CK>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, 0, kb, nullptr, tid);
+    stage_load<PR, CK>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, 0, kb, dinv, tid);
     for (int k0 = 0; k0 < kb; k0 += CK) {
       __syncthreads();
       stage_store<PR, CK>(sg, rg, tid);
       __syncthreads();
-      if (k0 + CK < kb) stage_load<PR, CK>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0 + CK, kb, nullptr, tid);
+      if (k0 + CK < kb) stage_load<PR, CK>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, k0 + CK, kb, dinv, tid);
       mfma_panel<PR, 2, 4, CK, true>(sg, 32 * wave, 0, lane, acc);
     }
   }
@@ -359,92 +379,187 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         // columns beyond the front's last one get a unit diagonal: they factorize to the identity
         P[col * LDQ + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
       }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int k = e & 63, n = e >> 6;
-    P[n * LDQ + PR + k] = (k == n) ? 1.0 : 0.0;
-  }
+  if (!LDL)
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int k = e & 63, n = e >> 6;
+      P[n * LDQ + PR + k] = (k == n) ? 1.0 : 0.0;
+    }
+  if (tid == 0) { s_neg = 0; s_two = 0; }
   __syncthreads();
   STAMP(2);
 
-  // ---- a. 16 x 16 Cholesky + inverse of the diagonal block at jb (one wave) --------------------------
-  auto chol16 = [&](int jb) {
+  // ---- a. 16 x 16 factorization + inverse of the diagonal block at jb (one wave) ---------------------
+  // LDL: pivots in the given order; hint[] (learned from the handle's previous pivoted factorization)
+  // says where a 2x2 pivot (j, j+1) is to be taken.  Every pivot and multiplier is tested; `bad`
+  // abandons the block to k_diag_ldlt.
+  auto fact16 = [&](int jb) {
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
       v[k] = (lane < 16) ? P[(jb + k) * LDQ + jb + lr] : ((lr == k) ? 1.0 : 0.0);
-    int failj = 16;
+    int failj = 16, nneg = 0, ntwo = 0;
+    unsigned hmask = 0;
+    if (LDL) {
+      const bool h2 = (lane < 16 && jb + lr < w) ? (hint[nd.sptr + kb + jb + lr] != 0) : false;
+      hmask = unsigned(__ballot(h2));
+    }
+    double p11[16], p21[16], p22[16];   // wave-uniform: inverted pivots (1x1: p11; 2x2 at j: p11,p21,p22 of (j,j+1))
+    bool second = false;                // wave-uniform: column j is the second of a 2x2 pivot
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
+      p11[j] = 1.0; p21[j] = 0.0; p22[j] = 0.0;
+      if (LDL && second) { second = false; continue; }
+      const bool want2 = LDL && ((hmask >> j) & 1u);
+      if (want2 && (j == 15 || jb + j + 1 >= w)) bad = true;      // the pair straddles this stage
+      if (LDL && want2 && j < 15 && jb + j + 1 < w) {
+        const double a11 = readlane_f64(v[j], j), a21 = readlane_f64(v[j], j + 1);
+        const double a22 = readlane_f64(v[j + 1], j + 1);
+        // acceptance and inverse as in block_ldlt.hxx:210-240 (test_2x2 / the scaled determinant)
+        if (!(fabs(a21) >= small)) bad = true;
+        const double detscale = 1.0 / fabs(a21);
+        const double detpiv = (a11 * detscale) * a22 - fabs(a21);
+        if (!(fabs(detpiv) >= fabs(a21) / 2)) bad = true;
+        const double d11 = (a22 * detscale) / detpiv, d22 = (a11 * detscale) / detpiv;
+        const double d21 = (-a21 * detscale) / detpiv;
+        const double own1 = d11 * v[j] + d21 * v[j + 1], own2 = d21 * v[j] + d22 * v[j + 1];
+        if (lane < 16 && lr > j + 1 && !(fabs(own1) <= inv_u && fabs(own2) <= inv_u)) bad = true;
+        const double u1 = (jb + lr < w) ? v[j] : 0.0, u2 = (jb + lr < w) ? v[j + 1] : 0.0;
+#pragma unroll
+        for (int k = j + 2; k < 16; ++k) {
+          const double l1 = readlane_f64(u1, k), l2 = readlane_f64(u2, k);
+          v[k] = fma(-own1, l1, fma(-own2, l2, v[k]));
+        }
+        if (lane < 16) {
+          v[j] = (lr == j) ? 1.0 : ((lr == j + 1) ? 0.0 : own1);
+          v[j + 1] = (lr == j + 1) ? 1.0 : own2;
+        }
+        p11[j] = d11; p21[j] = d21; p22[j] = d22;
+        const double det = a11 * a22 - a21 * a21;
+        if (det < 0.0) nneg += 1;
+        else if (a11 + a22 < 0.0) nneg += 2;
+        ++ntwo;
+        if (lane == 0) { dgs[2 * (jb + j)] = d11; dgs[2 * (jb + j) + 1] = d21; dgs[2 * (jb + j) + 2] = INFINITY; dgs[2 * (jb + j) + 3] = d22; }
+        second = true;
+        continue;
+      }
       const double d = readlane_f64(v[j], j);
-      if (!(d > 0.0)) failj = min(failj, j);
-      double y = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware estimate + two Newton steps
-      const double hd = 0.5 * d;
-      y = y * fma(-hd * y, y, 1.5);
-      y = y * fma(-hd * y, y, 1.5);
-      v[j] *= y;                                   // L rows: l_rj (lane j: sqrt(d)); identity lanes: x_j
+      double own;
+      if (LDL) {
+        if (jb + j < w) {
+          if (!(fabs(d) >= small)) bad = true;
+          if (d < 0.0) ++nneg;
+        }
+        double rd = __builtin_amdgcn_rcp(d);         // reciprocal + two Newton steps: full precision
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        own = v[j] * rd;                             // L rows: l_rj (lane j: 1); identity lanes: x_j / d
+        if (lane < 16 && lr > j && !(fabs(own) <= inv_u)) bad = true;   // threshold test inside the block
+        p11[j] = rd;
+        if (lane == 0) { dgs[2 * (jb + j)] = rd; dgs[2 * (jb + j) + 1] = 0.0; }
+      } else {
+        if (!(d > 0.0)) failj = min(failj, j);
+        double y = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware estimate + two Newton steps
+        const double hd = 0.5 * d;
+        y = y * fma(-hd * y, y, 1.5);
+        y = y * fma(-hd * y, y, 1.5);
+        v[j] *= y;                                   // L rows: l_rj (lane j: sqrt(d)); identity lanes: x_j
+        own = v[j];
+      }
       // columns >= w are padding (unit diagonal): rows >= w keep their l_rj but must not update them
-      const double u = (jb + lr < w) ? v[j] : 0.0;
+      const double um = (jb + lr < w) ? v[j] : 0.0;  // LDL: the unscaled a_kj
 #pragma unroll
       for (int k = j + 1; k < 16; ++k) {
-        const double lkj = readlane_f64(u, k);
-        v[k] = fma(-v[j], lkj, v[k]);
+        const double lkj = readlane_f64(um, k);
+        v[k] = fma(-own, lkj, v[k]);
       }
+      if (LDL && lane < 16) v[j] = own;              // the identity lanes keep x_j
     }
-    if (lane == 0 && failj < 16 && jb + failj < w) atomicMin(&stat[0], nd.sptr + kb + jb + failj);
+    if (!LDL && lane == 0 && failj < 16 && jb + failj < w) atomicMin(&stat[0], nd.sptr + kb + jb + failj);
+    if (LDL && lane == 0) { s_neg += nneg; s_two += ntwo; }   // only wave 0 ever runs this
     if (lane < 16) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) P[(jb + k) * LDQ + jb + lr] = (k <= lr) ? v[k] : 0.0;
     } else if (lane < 32) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) Xs[lr * 16 + k] = (k >= lr) ? v[k] : 0.0;
+      if (LDL) {   // Z = D16^-1 L16^-1, column lr
+        double z[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) z[k] = p11[k] * v[k];
+#pragma unroll
+        for (int k = 0; k + 1 < 16; ++k)
+          if (p22[k] != 0.0 || p21[k] != 0.0) {      // 2x2 pivot at (k, k+1)
+            z[k] = p11[k] * v[k] + p21[k] * v[k + 1];
+            z[k + 1] = p21[k] * v[k] + p22[k] * v[k + 1];
+          }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Zs[lr * 16 + k] = z[k];
+      }
     }
   };
-  if (wave == 0) chol16(0);
+  if (wave == 0) fact16(0);
   __syncthreads();
   for (int jb = 0; jb < NB; jb += 16) {
     STAMP(4 + 3 * (jb >> 4));
-    // ---- b. rows below: Y = R * L16^-T, computed transposed so that lanes run along the rows of P.
-    // Three row tiles per wave, no branches around the MFMAs: a tile index past the end is clamped to
-    // the last tile (computed again, not stored).
+    // ---- b. rows below: Y = R * L16^-T [* D16^-1], computed transposed so that lanes run along the rows
+    // of P.  Three row tiles per wave, no branches around the MFMAs: a tile index past the end is
+    // clamped to the last tile (computed again, not stored).
     {
       const int rt0 = (jb >> 4) + 1;
-      double4_t c[3];
-      double rb[3][4], xa[4];
+      double4_t c[3], cz[3];
+      double rb[3][4], xa[4], za[4];
       int rtc[3];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) xa[k] = Xs[(4 * k + lq) * 16 + lr];                  // A[i=n][k] = X[n][k]
+      for (int k = 0; k < 4; ++k) {
+        xa[k] = Xs[(4 * k + lq) * 16 + lr];                  // A[i=n][k] = X[n][k]
+        za[k] = LDL ? Zs[(4 * k + lq) * 16 + lr] : 0.0;
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        rtc[i] = min(rt0 + wave + 4 * i, PRX / 16 - 1);
+        rtc[i] = min(rt0 + wave + 4 * i, NRT - 1);
         c[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        cz[i] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) rb[i][k] = P[(jb + 4 * k + lq) * LDQ + 16 * rtc[i] + lr];   // B[k][j=row]
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k], rb[i][k], c[i], 0, 0, 0);
+        for (int i = 0; i < 3; ++i) {
+          c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k], rb[i][k], c[i], 0, 0, 0);
+          if (LDL) cz[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[k], rb[i][k], cz[i], 0, 0, 0);
+        }
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if (rt0 + wave + 4 * i < PRX / 16) {      // a clamped duplicate must not store: its inputs may be gone
+        if (rt0 + wave + 4 * i < NRT) {           // a clamped duplicate must not store: its inputs may be gone
 #pragma unroll
-          for (int r = 0; r < 4; ++r) P[(jb + lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = c[i][r];
+          for (int r = 0; r < 4; ++r) {
+            if (LDL) {
+              const double yv = cz[i][r];
+              if (!(fabs(yv) <= inv_u)) bad = true;   // a-posteriori threshold test on the rows below
+              P[(jb + lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = yv;           // Y = R L^-T D^-1 (the factor)
+              YP[(lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = c[i][r];          // Y' = R L^-T
+            } else {
+              P[(jb + lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = c[i][r];
+            }
+          }
         }
     }
     __syncthreads();
     STAMP(5 + 3 * (jb >> 4));
     if (jb + 16 < NB) {
+      const double* dsc = LDL ? YP : nullptr;
       // ---- c1. the next block column only, all waves ------------------------------------------------
       const int cj1 = (jb >> 4) + 1;
-      for (int rt = cj1 + wave; rt < PRX / 16; rt += 4) syrk_row<1>(P, LDQ, jb, rt, cj1, w, lr, lq);
+      for (int rt = cj1 + wave; rt < NRT; rt += 4) syrk_row<1>(P, LDQ, jb, rt, cj1, w, lr, lq, dsc);
       __syncthreads();
       // ---- wave 0 factorizes the next diagonal block while the others finish the trailing update -----
       if (wave == 0) {
-        chol16(jb + 16);
+        fact16(jb + 16);
       } else if (cj1 + 1 < NB / 16) {
-        for (int rt = cj1 + wave; rt < PRX / 16; rt += 3) {
-          if (min(NB / 16 - 1, rt) - cj1 == 2) syrk_row<2>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq);
-          else syrk_row<1>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq);
+        for (int rt = cj1 + wave; rt < NRT; rt += 3) {
+          if (min(NB / 16 - 1, rt) - cj1 == 2) syrk_row<2>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq, dsc);
+          else syrk_row<1>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq, dsc);
         }
       }
       __syncthreads();
@@ -452,6 +567,20 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     STAMP(6 + 3 * (jb >> 4));
   }
   STAMP(16);
+  if (LDL) {
+    const bool anybad = __syncthreads_or(bad);
+    if (tid == 0) {
+      fastok[nd.iblk + t.step] = anybad ? 0 : 1;
+      atomicAdd(&stat[anybad ? 7 : 6], 1);         // statistics: blocks done optimistically / redone with pivoting
+    }
+    if (anybad) return;                              // k_diag_ldlt takes the block from the untouched input
+    if (tid < w) {
+      D[2 * int64_t(nd.sptr + kb + tid)] = dgs[2 * tid];
+      D[2 * int64_t(nd.sptr + kb + tid) + 1] = dgs[2 * tid + 1];
+    }
+    if (tid == 0 && s_neg) atomicAdd(&stat[2], s_neg);
+    if (tid == 0 && s_two) atomicAdd(&stat[3], s_two);
+  }
   // ---- store L (lower trapezoid) and W = L11^-T; both coalesced along rows ---------------------------
   {
     const int row = tid & (PR - 1);
@@ -459,8 +588,10 @@ k_diag_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     for (int col = tid >> 7; col < w; col += 2)
       if (row >= col && row < pr) dst[int64_t(col) * nd.ld] = P[col * LDQ + row];
   }
-  double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
-  for (int e = tid; e < NB * NB; e += 256) W[e] = P[(e >> 6) * LDQ + PR + (e & 63)];
+  if (!LDL) {
+    double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
+    for (int e = tid; e < NB * NB; e += 256) W[e] = P[(e >> 6) * LDQ + PR + (e & 63)];
+  }
   STAMP(17);
 }
 
@@ -489,7 +620,8 @@ __device__ __forceinline__ void swap_sym(double* P, int32_t* lperm, int pr, int 
 __global__ void __launch_bounds__(256)
 k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
             double* __restrict__ L, double* __restrict__ D, int32_t* __restrict__ gperm,
-            int32_t* __restrict__ stat, int32_t* __restrict__ faillist, double small, double u) {
+            int32_t* __restrict__ stat, int32_t* __restrict__ faillist, const int32_t* __restrict__ fastok,
+            double small, double u) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);
@@ -501,6 +633,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 
   const PanelTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
+  if (fastok[nd.iblk + t.step]) return;      // the optimistic pass (k_diag_fast<true>) already did this block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kb = t.step * NB;
   const int w = min(NB, nd.n - kb);
@@ -1004,7 +1137,7 @@ k_panel_chol(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ t
 // contribution kernel: tile (ti,tj) of  C -= L21 * D * L21^T   (K = n, MFMA)
 // =================================================================================================
 template <bool POSDEF>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, POSDEF ? 3 : 2)
 k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks,
           const double* __restrict__ L, const double* __restrict__ D, double* __restrict__ C) {
   __shared__ Stage<TS, CK> sg;
@@ -1328,7 +1461,7 @@ k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
 
 // =================================================================================================
 // Cholesky solves with the inverted diagonal blocks (W = L11^-T, one 64 x 64 block per 64 pivots,
-// written by k_diag_chol): a block's triangular solve is a 64 x 64 matrix-vector product instead of
+// written by k_diag_fast): a block's triangular solve is a 64 x 64 matrix-vector product instead of
 // 64 dependent steps, and every load of a phase is issued before its first use.
 // One workgroup per front; r (LDS) holds the front's m entries: [0,n) pivots, [n,m) contribution rows.
 // =================================================================================================
@@ -1743,7 +1876,7 @@ void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.segC, F.segV, F.posowner};
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.fastok, F.hint, F.segC, F.segV, F.posowner};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -1751,7 +1884,8 @@ void dev_free(DeviceFactor& F) {
 
 static hipError_t allow_big_lds() {
   const int big = 160 * 1024 - 512;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -2022,6 +2156,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), std::max<int64_t>(F.cvec_elems, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), 16 * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.faillist), FAILCAP * sizeof(int32_t)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.fastok), std::max<int64_t>(F.nblk64, 1) * sizeof(int32_t)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.hint), std::max(S.n, 1)));
+  HIPCHK(hipMemsetAsync(F.hint, 0, std::max(S.n, 1), st));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
   return hipSuccess;
 }
@@ -2033,6 +2170,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
   const size_t lds_chol = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * NB);
+  const size_t lds_fldl = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * (NB + 16));
   const size_t lds_pchol = std::max(sizeof(Stage<RB, CK>), sizeof(double) * (2 * NB * RBP));
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
@@ -2043,12 +2181,16 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
     const int nsteps = int(lp.panel_cnt.size() / 2);
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
-        if (POSDEF)
-          hipLaunchKernelGGL(k_diag_chol, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_chol, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.stat);
-        else
+        if (POSDEF) {
+          hipLaunchKernelGGL(k_diag_fast<false>, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_chol, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u);
+        } else {
+          hipLaunchKernelGGL(k_diag_fast<true>, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_fldl, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u);
           hipLaunchKernelGGL(k_diag_ldlt, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, F.faillist, small, u);
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, F.faillist, F.fastok,
+                             small, u);
+        }
       }
       if (lp.panel_cnt[2 * s + 1] > 0) {
         if (POSDEF)

@@ -91,6 +91,8 @@ struct DeviceFactor {
   double* L = nullptr;
   double* Linv = nullptr;        // Cholesky only: L11^-T of every 64-column block, nblk64 x 64 x 64
   int64_t nblk64 = 0;
+  uint8_t* hint = nullptr;       // LDL^T: 1 at the first position of a 2x2 pivot learned from an earlier factorization
+  int32_t* fastok = nullptr;     // LDL^T: 1 = the optimistic block pass succeeded (per 64-column block)
   double* C = nullptr;         // contribution arena
   double* D = nullptr;         // 2*n inverted pivots in pivot order (indefinite)
   double* val = nullptr;       // staging for host-supplied values

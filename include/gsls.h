@@ -210,6 +210,10 @@ int gsls_get_symbolic_sizes(void* handle, int32_t* nnodes, int64_t* rlist_len, i
 int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rptr, int32_t* rlist,
                       int64_t* nptr, int64_t* nlist);
 
+/* the elimination order the handle currently holds (order[var] = 1-based pivot position): what analyse was
+ * given or computed, as repaired by factorizations that met delayed pivots; a valid PERM for SLS_analyse */
+int gsls_get_order(void* handle, int32_t* order);
+
 /* stream the handle launches on (hipStream_t as void*), and per-phase kernel timing of the last
  * solve measured with HIP events on that stream (seconds); used by bench.py's roofline block. */
 void* gsls_get_stream(void* handle);
