@@ -26,7 +26,7 @@ struct Handle {
   Symbolic S;
   DeviceFactor F;
   bool analysed = false, factored = false, posdef = false, dev_ready = false, have_scale = false;
-  bool learned = false;       // the in-block pivot sequence of a pivoted factorization has been folded into the order
+  int learned = 0;            // rounds of folding the in-block pivot sequence of a pivoted factorization into the order
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -197,7 +197,8 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
     options = &defo;
   }
   const double t0 = now();
-  h->analysed = h->factored = h->dev_ready = h->learned = false;
+  h->analysed = h->factored = h->dev_ready = false;
+  h->learned = 0;
   if (n < 0) return inform->flag = GSLS_ERROR_A_N_OOR;
   if (n > 0 && (!ptr || !row)) return inform->flag = GSLS_ERROR_A_PTR;
   if (n > 0 && ptr[0] != 1) return inform->flag = GSLS_ERROR_A_PTR;
@@ -308,12 +309,12 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     if (getenv("GSLS_DEBUG"))
-      fprintf(stderr, "[gsls] pass %d: blocks fast %d, pivoted %d, failed columns %d, 2x2 %d\n", pass, st[6], st[7], st[4], st[3]);
-    if (!posdef && st[4] == 0 && !h->learned && st[7] > 0) {
+      fprintf(stderr, "[gsls] pass %d: blocks fast %d, pivoted %d, failed columns %d, 2x2 %d | why: small %d inblock %d straddle %d rej2x2 %d below %d\n", pass, st[6], st[7], st[4], st[3], st[8], st[9], st[10], st[11], st[12]);
+    if (!posdef && st[4] == 0 && h->learned < 3 && st[7] > 0) {
       // ---- learn: fold the pivot sequence the complete-pivoting kernel chose inside its blocks into the
       // elimination order, and remember where it took 2x2 pivots, so that later factorizations of
       // this pattern (the next interior-point iterations) go through the optimistic kernel
-      h->learned = true;
+      h->learned += 1;
       const int n = h->S.n;
       std::vector<int32_t> gp(n);
       std::vector<double> Dh(2 * size_t(n) + 4);
@@ -324,11 +325,29 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       std::vector<uint8_t> hints(n, 0);
       bool moved = false, any2 = false;
       std::vector<int32_t> order(n);
+      std::vector<int32_t> seq(n);     // seq[slot] = variable eliminated there
       for (int i = 0; i < n; ++i) {
-        order[h->S.invp[gp[i]]] = i + 1;
+        seq[i] = h->S.invp[gp[i]];
         moved |= (gp[i] != i);
         if (i + 1 < n && std::isinf(Dh[2 * size_t(i) + 2])) { hints[i] = 1; any2 = true; }
       }
+      // a 2x2 pivot must not straddle a 16-column stage of the optimistic kernel: pull it one slot
+      // forward past a preceding 1x1 pivot of the same 64-column block
+      for (int s = 0; s < h->S.nnodes; ++s)
+        for (int pos = h->S.sptr[s]; pos + 1 < h->S.sptr[s + 1]; ++pos) {
+          const int rel = pos - h->S.sptr[s];
+          if (!hints[pos] || (rel & 15) != 15) continue;
+          if ((rel & 63) == 0 || hints[pos - 1]) continue;
+          if (rel >= 2 && hints[pos - 2]) continue;          // pos-1 is the second half of a pair
+          const int a = seq[pos - 1];
+          seq[pos - 1] = seq[pos];
+          seq[pos] = seq[pos + 1];
+          seq[pos + 1] = a;
+          hints[pos - 1] = 1;
+          hints[pos] = 0;
+          moved = true;
+        }
+      for (int i = 0; i < n; ++i) order[seq[i]] = i + 1;
       if (moved) {
         int flag2;
         try {
@@ -367,7 +386,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       return inform->flag;
     }
     total_moved += int(failed.size());
-    h->learned = false;   // the order changes: learn the in-block pivot sequence again afterwards
+    h->learned = 0;       // the order changes: learn the in-block pivot sequence again afterwards
     int flag2;
     try {
       flag2 = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER,

@@ -334,6 +334,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   const double* dinv = LDL ? (D + 2 * int64_t(nd.sptr)) : nullptr;
   const double inv_u = (LDL && u > 0.0) ? 1.0 / u : INFINITY;
   bool bad = false;
+  int why = 0;   // diagnostics only (GSLS_DEBUG): which test abandoned the block
 
   STAMP(0);
   // the block's own entries first: their latency hides behind the left-looking update.  Tiles are
@@ -410,19 +411,19 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       p11[j] = 1.0; p21[j] = 0.0; p22[j] = 0.0;
       if (LDL && second) { second = false; continue; }
       const bool want2 = LDL && ((hmask >> j) & 1u);
-      if (want2 && (j == 15 || jb + j + 1 >= w)) bad = true;      // the pair straddles this stage
+      if (want2 && (j == 15 || jb + j + 1 >= w)) { bad = true; why |= 4; }      // the pair straddles this stage
       if (LDL && want2 && j < 15 && jb + j + 1 < w) {
         const double a11 = readlane_f64(v[j], j), a21 = readlane_f64(v[j], j + 1);
         const double a22 = readlane_f64(v[j + 1], j + 1);
         // acceptance and inverse as in block_ldlt.hxx:210-240 (test_2x2 / the scaled determinant)
-        if (!(fabs(a21) >= small)) bad = true;
+        if (!(fabs(a21) >= small)) { bad = true; why |= 8; }
         const double detscale = 1.0 / fabs(a21);
         const double detpiv = (a11 * detscale) * a22 - fabs(a21);
-        if (!(fabs(detpiv) >= fabs(a21) / 2)) bad = true;
+        if (!(fabs(detpiv) >= fabs(a21) / 2)) { bad = true; why |= 8; }
         const double d11 = (a22 * detscale) / detpiv, d22 = (a11 * detscale) / detpiv;
         const double d21 = (-a21 * detscale) / detpiv;
         const double own1 = d11 * v[j] + d21 * v[j + 1], own2 = d21 * v[j] + d22 * v[j + 1];
-        if (lane < 16 && lr > j + 1 && !(fabs(own1) <= inv_u && fabs(own2) <= inv_u)) bad = true;
+        if (lane < 16 && lr > j + 1 && !(fabs(own1) <= inv_u && fabs(own2) <= inv_u)) { bad = true; why |= 2; }
         const double u1 = (jb + lr < w) ? v[j] : 0.0, u2 = (jb + lr < w) ? v[j + 1] : 0.0;
 #pragma unroll
         for (int k = j + 2; k < 16; ++k) {
@@ -446,14 +447,14 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       double own;
       if (LDL) {
         if (jb + j < w) {
-          if (!(fabs(d) >= small)) bad = true;
+          if (!(fabs(d) >= small)) { bad = true; why |= 1; }
           if (d < 0.0) ++nneg;
         }
         double rd = __builtin_amdgcn_rcp(d);         // reciprocal + two Newton steps: full precision
         rd = fma(fma(-d, rd, 1.0), rd, rd);
         rd = fma(fma(-d, rd, 1.0), rd, rd);
         own = v[j] * rd;                             // L rows: l_rj (lane j: 1); identity lanes: x_j / d
-        if (lane < 16 && lr > j && !(fabs(own) <= inv_u)) bad = true;   // threshold test inside the block
+        if (lane < 16 && lr > j && !(fabs(own) <= inv_u)) { bad = true; why |= 2; }   // threshold test inside the block
         p11[j] = rd;
         if (lane == 0) { dgs[2 * (jb + j)] = rd; dgs[2 * (jb + j) + 1] = 0.0; }
       } else {
@@ -536,7 +537,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
           for (int r = 0; r < 4; ++r) {
             if (LDL) {
               const double yv = cz[i][r];
-              if (!(fabs(yv) <= inv_u)) bad = true;   // a-posteriori threshold test on the rows below
+              if (!(fabs(yv) <= inv_u)) { bad = true; why |= 16; }   // a-posteriori threshold test on the rows below
               P[(jb + lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = yv;           // Y = R L^-T D^-1 (the factor)
               YP[(lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = c[i][r];          // Y' = R L^-T
             } else {
@@ -569,6 +570,8 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   STAMP(16);
   if (LDL) {
     const bool anybad = __syncthreads_or(bad);
+    for (int b2 = 0; b2 < 5; ++b2)
+      if (__syncthreads_or((why >> b2) & 1) && tid == 0) atomicAdd(&stat[8 + b2], 1);
     if (tid == 0) {
       fastok[nd.iblk + t.step] = anybad ? 0 : 1;
       atomicAdd(&stat[anybad ? 7 : 6], 1);         // statistics: blocks done optimistically / redone with pivoting

@@ -1,0 +1,19 @@
+import csv,glob,sys,collections
+d=sys.argv[1]
+f=glob.glob(d+'/*/*_kernel_trace.csv')[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+idx=[i for i,r in enumerate(rows) if 'k_iota' in r['Kernel_Name']]
+a=idx[-1]
+seg=rows[a-3:]
+agg=collections.OrderedDict()
+for r in seg:
+    k=r['Kernel_Name'][:34]
+    du=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
+    c,t,mx=agg.get(k,(0,0.0,0.0)); agg[k]=(c+1,t+du,max(mx,du))
+tot=(int(seg[-1]['End_Timestamp'])-int(seg[0]['Start_Timestamp']))/1e3
+print('last step: %d kernels, %.1f us wall'%(len(seg),tot))
+for k,(c,t,mx) in sorted(agg.items(),key=lambda x:-x[1][1]):
+    print(k.ljust(36),str(c).rjust(4),'%9.1f us total %8.1f avg %8.1f max'%(t,t/c,mx))
+if len(sys.argv)>2:
+    for r in seg: print(r['Kernel_Name'][:30].ljust(30),(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3, r.get('Grid_Size_X',r.get('Grid_Size','?')))
