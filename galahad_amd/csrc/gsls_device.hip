@@ -307,21 +307,25 @@ __device__ __forceinline__ void syrk_row(double* P, int ldq, int jb, int rt, int
 // fails anywhere in the block nothing is stored and fastok[block] = 0: k_diag_ldlt (complete pivoting,
 // 2x2 pivots) then redoes that block; blocks that pass are skipped by it.  (Optimistic first, robust
 // fallback: the a-posteriori idea of ldlt_app.cxx:303-321 at block granularity.)
-template <bool LDL>
-__global__ void __launch_bounds__(256)
+// GEMM = false: first block column of a front (nothing to the left): no update code, fewer registers
+template <bool LDL, bool GEMM>
+__global__ void __launch_bounds__(256, LDL ? (GEMM ? 2 : 3) : 1)
 k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
             double* __restrict__ L, double* __restrict__ Linv, double* __restrict__ D,
             int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
-            double small, double u) {
+            double small, double u, int ldq_arg, int nrt_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR, CK>& sg = *reinterpret_cast<Stage<PR, CK>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);  // [NB][LDQ], overlays the staging buffers after the GEMM
-  double* YP = P + NB * LDQ;                        // LDL: [16][LDQ], Y' = R L16^-T of the current stage
+  // LDL: the panel is only as tall as the launch's tallest front (ldq, nrt from the host): several small
+  // fronts share a CU.  Cholesky keeps compile-time constants.
+  const int ldq = LDL ? ldq_arg : LDQ;
+  const int nrt = LDL ? nrt_arg : PRX / 16;       // row tiles: the identity rows (W) only for Cholesky
+  double* YP = P + NB * ldq;                        // LDL: [16][ldq], Y' = R L16^-T of the current stage
   __shared__ double Xs[16 * 16];                    // Xs[k][n] = (L16^-1)[n][k]
   __shared__ double Zs[16 * 16];                    // LDL: Zs[k][n] = (D16^-1 L16^-1)[n][k]
   __shared__ double dgs[2 * NB + 4];                // LDL: inverted pivots in the layout of D
   __shared__ int32_t s_neg, s_two;
-  constexpr int NRT = (LDL ? PR : PRX) / 16;        // row tiles: the identity rows (W) only for Cholesky
 
   const PanelTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
@@ -356,7 +360,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  if (kb > 0) {
+  if (GEMM && kb > 0) {
     StageRegs<PR, CK> rg;
     stage_load<PR, CK>(rg, Lb, nd.ld, kb, nd.m, kb, kb + w, 0, kb, dinv, tid);
     for (int k0 = 0; k0 < kb; k0 += CK) {
@@ -378,12 +382,13 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         const int row = 32 * wave + 16 * i + lr;
         const int col = 16 * j + lq + 4 * r;
         // columns beyond the front's last one get a unit diagonal: they factorize to the identity
-        P[col * LDQ + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
+        if (!LDL || row < 16 * nrt)
+          P[col * ldq + row] = (row < pr && col < w) ? g[i][j][r] - acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
       }
   if (!LDL)
     for (int e = tid; e < NB * NB; e += 256) {
       const int k = e & 63, n = e >> 6;
-      P[n * LDQ + PR + k] = (k == n) ? 1.0 : 0.0;
+      P[n * ldq + PR + k] = (k == n) ? 1.0 : 0.0;
     }
   if (tid == 0) { s_neg = 0; s_two = 0; }
   __syncthreads();
@@ -397,18 +402,16 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-      v[k] = (lane < 16) ? P[(jb + k) * LDQ + jb + lr] : ((lr == k) ? 1.0 : 0.0);
+      v[k] = (lane < 16) ? P[(jb + k) * ldq + jb + lr] : ((lr == k) ? 1.0 : 0.0);
     int failj = 16, nneg = 0, ntwo = 0;
     unsigned hmask = 0;
     if (LDL) {
       const bool h2 = (lane < 16 && jb + lr < w) ? (hint[nd.sptr + kb + jb + lr] != 0) : false;
       hmask = unsigned(__ballot(h2));
     }
-    double p11[16], p21[16], p22[16];   // wave-uniform: inverted pivots (1x1: p11; 2x2 at j: p11,p21,p22 of (j,j+1))
     bool second = false;                // wave-uniform: column j is the second of a 2x2 pivot
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      p11[j] = 1.0; p21[j] = 0.0; p22[j] = 0.0;
       if (LDL && second) { second = false; continue; }
       const bool want2 = LDL && ((hmask >> j) & 1u);
       if (want2 && (j == 15 || jb + j + 1 >= w)) { bad = true; why |= 4; }      // the pair straddles this stage
@@ -434,7 +437,6 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
           v[j] = (lr == j) ? 1.0 : ((lr == j + 1) ? 0.0 : own1);
           v[j + 1] = (lr == j + 1) ? 1.0 : own2;
         }
-        p11[j] = d11; p21[j] = d21; p22[j] = d22;
         const double det = a11 * a22 - a21 * a21;
         if (det < 0.0) nneg += 1;
         else if (a11 + a22 < 0.0) nneg += 2;
@@ -455,7 +457,6 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         rd = fma(fma(-d, rd, 1.0), rd, rd);
         own = v[j] * rd;                             // L rows: l_rj (lane j: 1); identity lanes: x_j / d
         if (lane < 16 && lr > j && !(fabs(own) <= inv_u)) { bad = true; why |= 2; }   // threshold test inside the block
-        p11[j] = rd;
         if (lane == 0) { dgs[2 * (jb + j)] = rd; dgs[2 * (jb + j) + 1] = 0.0; }
       } else {
         if (!(d > 0.0)) failj = min(failj, j);
@@ -476,29 +477,34 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       if (LDL && lane < 16) v[j] = own;              // the identity lanes keep x_j
     }
     if (!LDL && lane == 0 && failj < 16 && jb + failj < w) atomicMin(&stat[0], nd.sptr + kb + jb + failj);
-    if (LDL && lane == 0) { s_neg += nneg; s_two += ntwo; }   // only wave 0 ever runs this
+    if (LDL && lane == 0) { s_neg += nneg; s_two += ntwo; }   // only one wave ever runs this
     if (lane < 16) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) P[(jb + k) * LDQ + jb + lr] = (k <= lr) ? v[k] : 0.0;
+      for (int k = 0; k < 16; ++k) P[(jb + k) * ldq + jb + lr] = (k <= lr) ? v[k] : 0.0;
     } else if (lane < 32) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) Xs[lr * 16 + k] = (k >= lr) ? v[k] : 0.0;
-      if (LDL) {   // Z = D16^-1 L16^-1, column lr
+      if (LDL) {   // Z = D16^-1 L16^-1, column lr; the pivots come back from LDS (dgs, written by lane 0)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         double z[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) z[k] = p11[k] * v[k];
+        for (int k = 0; k < 16; ++k) z[k] = dgs[2 * (jb + k)] * v[k];
 #pragma unroll
         for (int k = 0; k + 1 < 16; ++k)
-          if (p22[k] != 0.0 || p21[k] != 0.0) {      // 2x2 pivot at (k, k+1)
-            z[k] = p11[k] * v[k] + p21[k] * v[k + 1];
-            z[k + 1] = p21[k] * v[k] + p22[k] * v[k + 1];
+          if (isinf(dgs[2 * (jb + k) + 2])) {        // 2x2 pivot at (k, k+1): [d11, d21, inf, d22]
+            const double d11 = dgs[2 * (jb + k)], d21 = dgs[2 * (jb + k) + 1], d22 = dgs[2 * (jb + k) + 3];
+            z[k] = d11 * v[k] + d21 * v[k + 1];
+            z[k + 1] = d21 * v[k] + d22 * v[k + 1];
           }
 #pragma unroll
         for (int k = 0; k < 16; ++k) Zs[lr * 16 + k] = z[k];
       }
     }
   };
-  if (wave == 0) fact16(0);
+  // the wave that runs the serial 16 x 16 stages rotates with the workgroup index, so that workgroups
+  // sharing a CU do not queue their serial stages on the same SIMD
+  const int fw = blockIdx.x & 3;
+  if (wave == fw) fact16(0);
   __syncthreads();
   for (int jb = 0; jb < NB; jb += 16) {
     STAMP(4 + 3 * (jb >> 4));
@@ -517,11 +523,11 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        rtc[i] = min(rt0 + wave + 4 * i, NRT - 1);
+        rtc[i] = min(rt0 + wave + 4 * i, nrt - 1);
         c[i] = double4_t{0.0, 0.0, 0.0, 0.0};
         cz[i] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rb[i][k] = P[(jb + 4 * k + lq) * LDQ + 16 * rtc[i] + lr];   // B[k][j=row]
+        for (int k = 0; k < 4; ++k) rb[i][k] = P[(jb + 4 * k + lq) * ldq + 16 * rtc[i] + lr];   // B[k][j=row]
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -532,16 +538,16 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         }
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if (rt0 + wave + 4 * i < NRT) {           // a clamped duplicate must not store: its inputs may be gone
+        if (rt0 + wave + 4 * i < nrt) {           // a clamped duplicate must not store: its inputs may be gone
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (LDL) {
               const double yv = cz[i][r];
               if (!(fabs(yv) <= inv_u)) { bad = true; why |= 16; }   // a-posteriori threshold test on the rows below
-              P[(jb + lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = yv;           // Y = R L^-T D^-1 (the factor)
-              YP[(lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = c[i][r];          // Y' = R L^-T
+              P[(jb + lq + 4 * r) * ldq + 16 * rtc[i] + lr] = yv;           // Y = R L^-T D^-1 (the factor)
+              YP[(lq + 4 * r) * ldq + 16 * rtc[i] + lr] = c[i][r];          // Y' = R L^-T
             } else {
-              P[(jb + lq + 4 * r) * LDQ + 16 * rtc[i] + lr] = c[i][r];
+              P[(jb + lq + 4 * r) * ldq + 16 * rtc[i] + lr] = c[i][r];
             }
           }
         }
@@ -552,15 +558,15 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       const double* dsc = LDL ? YP : nullptr;
       // ---- c1. the next block column only, all waves ------------------------------------------------
       const int cj1 = (jb >> 4) + 1;
-      for (int rt = cj1 + wave; rt < NRT; rt += 4) syrk_row<1>(P, LDQ, jb, rt, cj1, w, lr, lq, dsc);
+      for (int rt = cj1 + wave; rt < nrt; rt += 4) syrk_row<1>(P, ldq, jb, rt, cj1, w, lr, lq, dsc);
       __syncthreads();
       // ---- wave 0 factorizes the next diagonal block while the others finish the trailing update -----
-      if (wave == 0) {
+      if (wave == fw) {
         fact16(jb + 16);
       } else if (cj1 + 1 < NB / 16) {
-        for (int rt = cj1 + wave; rt < NRT; rt += 3) {
-          if (min(NB / 16 - 1, rt) - cj1 == 2) syrk_row<2>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq, dsc);
-          else syrk_row<1>(P, LDQ, jb, rt, cj1 + 1, w, lr, lq, dsc);
+        for (int rt = cj1 + 1 + ((wave - fw - 1) & 3); rt < nrt; rt += 3) {
+          if (min(NB / 16 - 1, rt) - cj1 == 2) syrk_row<2>(P, ldq, jb, rt, cj1 + 1, w, lr, lq, dsc);
+          else syrk_row<1>(P, ldq, jb, rt, cj1 + 1, w, lr, lq, dsc);
         }
       }
       __syncthreads();
@@ -589,11 +595,11 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     const int row = tid & (PR - 1);
     double* dst = Lb + int64_t(kb) * nd.ld + kb + row;
     for (int col = tid >> 7; col < w; col += 2)
-      if (row >= col && row < pr) dst[int64_t(col) * nd.ld] = P[col * LDQ + row];
+      if (row >= col && row < pr) dst[int64_t(col) * nd.ld] = P[col * ldq + row];
   }
   if (!LDL) {
     double* W = Linv + (int64_t(nd.iblk) + t.step) * (NB * NB);
-    for (int e = tid; e < NB * NB; e += 256) W[e] = P[(e >> 6) * LDQ + PR + (e & 63)];
+    for (int e = tid; e < NB * NB; e += 256) W[e] = P[(e >> 6) * ldq + PR + (e & 63)];
   }
   STAMP(17);
 }
@@ -1656,6 +1662,95 @@ k_solve_bwd_chol(const SolveTask* __restrict__ tasks, const int32_t* __restrict_
 }
 
 // =================================================================================================
+// LDL^T solves for TINY fronts (n <= 64 pivots, m - n <= 64 rows below): one WAVE per front, four fronts per
+// workgroup, no barriers.  Trees of saddle-point systems are tens of thousands of such fronts; a
+// workgroup per front left the CU mostly idle.  Row/column of the front live in registers, the
+// 64-step recurrences run on v_readlane broadcasts, rows are read coalesced (forward) or as one
+// contiguous column per lane (backward).
+// =================================================================================================
+constexpr int TINY_M = 128;
+
+__global__ void __launch_bounds__(256)
+k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const NodeDesc* __restrict__ nodes,
+                 const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
+                 const int32_t* __restrict__ gperm, const double* __restrict__ L,
+                 double* __restrict__ xp, double* __restrict__ cvec) {
+  __shared__ double rsh[4][TINY_M];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ti = blockIdx.x * 4 + wave;
+  if (ti >= ntask) return;
+  const SolveTask nd = tasks[ti];
+  const int n = nd.n, m = nd.m, cm = m - n;
+  double* r = rsh[wave];
+  const double* Lb = L + nd.loff;
+  // row `lane` of the unit lower L11 and row n+lane of L21: coalesced along the lanes, all in flight
+  double row[64], low[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) row[k] = (lane < n && k < lane) ? Lb[int64_t(k) * nd.ld + lane] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) low[k] = (lane < cm && k < n) ? Lb[int64_t(k) * nd.ld + n + lane] : 0.0;
+  const int pslot = (lane < n) ? gperm[nd.sptr + lane] - nd.sptr : 0;   // pivot `lane` sits at this analyse position
+  for (int i = lane; i < m; i += 64) r[i] = (i < n) ? xp[nd.sptr + i] : 0.0;
+  for (int ci = nd.cbeg; ci < nd.cend; ++ci) {   // children in order; a child's targets are distinct
+    int64_t moff;
+    int ccm;
+    if (ci == nd.cbeg) { moff = nd.cmoff0; ccm = nd.ccm0; }
+    else if (ci == nd.cbeg + 1) { moff = nd.cmoff1; ccm = nd.ccm1; }
+    else { const NodeDesc cn = nodes[clist[ci]]; moff = cn.moff; ccm = cn.m - cn.n; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (int i = lane; i < ccm; i += 64) r[cmap[moff + i]] += cvec[moff + i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  double yv = (lane < n) ? r[pslot] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {      // unit lower triangular solve, one pivot per step
+    const double yk = readlane_f64(yv, k);
+    yv = fma(-row[k], yk, yv);        // row[k] = 0 for k >= lane
+  }
+  if (lane < n) xp[nd.sptr + pslot] = yv;
+  double acc = (lane < cm) ? r[n + lane] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) acc = fma(-low[k], readlane_f64(yv, k), acc);
+  if (lane < cm) cvec[nd.moff + lane] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_solve_bwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* __restrict__ rlist,
+                 const int32_t* __restrict__ gperm, const double* __restrict__ L, double* __restrict__ xp) {
+  __shared__ double zsh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ti = blockIdx.x * 4 + wave;
+  if (ti >= ntask) return;
+  const SolveTask nd = tasks[ti];
+  const int n = nd.n, m = nd.m, cm = m - n;
+  double* z = zsh[wave];
+  const double* col = L + nd.loff + int64_t(lane) * nd.ld;   // column `lane`: one contiguous stream per lane
+  double up[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) up[j] = (lane < n && j > lane && j < n) ? col[j] : 0.0;   // L11(j, lane)
+  const int pslot = (lane < n) ? gperm[nd.sptr + lane] : 0;
+  double xv = (lane < n) ? xp[pslot] : 0.0;
+  if (lane < cm) z[lane] = xp[rlist[nd.roff + n + lane]];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  if (lane < n) {
+    double s0 = 0.0, s1 = 0.0;
+    int i = 0;
+    for (; i + 1 < cm; i += 2) {
+      s0 = fma(col[n + i], z[i], s0);
+      s1 = fma(col[n + i + 1], z[i + 1], s1);
+    }
+    if (i < cm) s0 = fma(col[n + i], z[i], s0);
+    xv -= s0 + s1;
+  }
+#pragma unroll
+  for (int j = 63; j >= 0; --j) {     // unit upper triangular solve, last pivot first
+    const double xj = readlane_f64(xv, j);
+    xv = fma(-up[j], xj, xv);         // up[j] = 0 for j <= lane
+  }
+  if (lane < n) xp[pslot] = xv;
+}
+
+// =================================================================================================
 // Solve path for BIG fronts (n > BIG_N or m > BIG_M): the front does not fit one workgroup's LDS and
 // one CU cannot stream it fast enough, so every 64-column block becomes two launches -- a 64 x 64
 // triangular solve (one workgroup per front) and a GEMV over the rows below it split into 256-row
@@ -1887,8 +1982,9 @@ void dev_free(DeviceFactor& F) {
 
 static hipError_t allow_big_lds() {
   const int big = 160 * 1024 - 512;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_chol), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -1964,11 +2060,15 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     // per step: diag tasks first, then the extra row chunks
     lp.panel_begin.assign(2 * maxsteps, 0);
     lp.panel_cnt.assign(2 * maxsteps, 0);
+    lp.panel_rows.assign(maxsteps, 0);
     for (int st_ = 0; st_ < maxsteps; ++st_) {
       lp.panel_begin[2 * st_] = int(pt.size());
       for (int i = lp.node_begin; i < lp.node_end; ++i) {
         const int s = lvl_nodes[i];
-        if (S.ncol(s) > st_ * NB) pt.push_back(PanelTask{s, st_, 0, 0});
+        if (S.ncol(s) > st_ * NB) {
+          pt.push_back(PanelTask{s, st_, 0, 0});
+          lp.panel_rows[st_] = std::max(lp.panel_rows[st_], std::min(PR, S.nrow(s) - st_ * NB));
+        }
       }
       lp.panel_cnt[2 * st_] = int(pt.size()) - lp.panel_begin[2 * st_];
       lp.panel_begin[2 * st_ + 1] = int(pt.size());
@@ -2017,17 +2117,24 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     lp.big_begin = int(bign.size());
     lp.small_maxn = lp.small_maxm = 0;
     int big_maxn = 0;
-    for (int i = lp.node_begin; i < lp.node_end; ++i) {
-      const int s = lvl_nodes[i];
-      if (S.ncol(s) > BIG_N || S.nrow(s) > BIG_M) {
-        bign.push_back(s);
-        big_maxn = std::max(big_maxn, S.ncol(s));
-      } else {
-        smalln.push_back(s);
-        lp.small_maxn = std::max(lp.small_maxn, S.ncol(s));
-        lp.small_maxm = std::max(lp.small_maxm, S.nrow(s));
+    lp.tiny_cnt = 0;
+    for (int pass = 0; pass < 2; ++pass)      // tiny fronts first: the LDL^T solves give them a wave each
+      for (int i = lp.node_begin; i < lp.node_end; ++i) {
+        const int s = lvl_nodes[i];
+        const bool big = S.ncol(s) > BIG_N || S.nrow(s) > BIG_M;
+        const bool tiny = S.ncol(s) <= 64 && S.nrow(s) - S.ncol(s) <= 64;
+        if (big) {
+          if (pass == 0) {
+            bign.push_back(s);
+            big_maxn = std::max(big_maxn, S.ncol(s));
+          }
+        } else if (tiny == (pass == 0)) {
+          smalln.push_back(s);
+          if (tiny) lp.tiny_cnt++;
+          lp.small_maxn = std::max(lp.small_maxn, S.ncol(s));
+          lp.small_maxm = std::max(lp.small_maxm, S.nrow(s));
+        }
       }
-    }
     lp.small_cnt = int(smalln.size()) - lp.small_begin;
     lp.big_cnt = int(bign.size()) - lp.big_begin;
     lp.bigsteps.clear();
@@ -2173,7 +2280,6 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
   const size_t lds_chol = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * NB);
-  const size_t lds_fldl = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * (NB + 16));
   const size_t lds_pchol = std::max(sizeof(Stage<RB, CK>), sizeof(double) * (2 * NB * RBP));
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
@@ -2185,11 +2291,22 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
         if (POSDEF) {
-          hipLaunchKernelGGL(k_diag_fast<false>, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_chol, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u);
+          hipLaunchKernelGGL((k_diag_fast<false, true>), dim3(lp.panel_cnt[2 * s]), dim3(256), lds_chol, st, F.nodes,
+                             F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u,
+                             LDQ, PRX / 16);
         } else {
-          hipLaunchKernelGGL(k_diag_fast<true>, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_fldl, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u);
+          // the LDS panel is as tall as this launch's tallest front: small fronts share a CU
+          const int nrt = std::max(NB / 16, (lp.panel_rows[s] + 15) / 16);
+          const int ldq = (16 * nrt) % 32 == 16 ? 16 * nrt : 16 * nrt + 16;
+          const size_t lds_fldl = std::max(s > 0 ? sizeof(Stage<PR, CK>) : size_t(0), sizeof(double) * ldq * (NB + 16));
+          if (s == 0)
+            hipLaunchKernelGGL((k_diag_fast<true, false>), dim3(lp.panel_cnt[2 * s]), dim3(256), lds_fldl, st, F.nodes,
+                               F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u,
+                               ldq, nrt);
+          else
+            hipLaunchKernelGGL((k_diag_fast<true, true>), dim3(lp.panel_cnt[2 * s]), dim3(256), lds_fldl, st, F.nodes,
+                               F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u,
+                               ldq, nrt);
           hipLaunchKernelGGL(k_diag_ldlt, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
                              F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, F.faillist, F.fastok,
                              small, u);
@@ -2257,10 +2374,16 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
                              sizeof(double) * (((lp.small_maxm + 63) & ~63) + 256), st, F.nodes,
                              static_cast<const SolveTask*>(F.stasks) + lp.small_begin, F.clist, F.cmap, F.L, F.Linv,
                              xp, F.cvec);
-        else
-          hipLaunchKernelGGL(k_solve_fwd<false>, dim3(lp.small_cnt), dim3(256),
-                             sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
-                             F.smallnodes + lp.small_begin, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+        else {
+          const SolveTask* stk = static_cast<const SolveTask*>(F.stasks) + lp.small_begin;
+          if (lp.tiny_cnt > 0)
+            hipLaunchKernelGGL(k_solve_fwd_tiny, dim3((lp.tiny_cnt + 3) / 4), dim3(256), 0, st, stk, lp.tiny_cnt,
+                               F.nodes, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+          if (lp.small_cnt > lp.tiny_cnt)
+            hipLaunchKernelGGL(k_solve_fwd<false>, dim3(lp.small_cnt - lp.tiny_cnt), dim3(256),
+                               sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
+                               F.smallnodes + lp.small_begin + lp.tiny_cnt, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+        }
       }
       if (lp.big_cnt > 0) {
         hipLaunchKernelGGL(k_big_fwd_prep<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
@@ -2307,10 +2430,16 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
           hipLaunchKernelGGL(k_solve_bwd_chol, dim3(lp.small_cnt), dim3(256),
                              sizeof(double) * (64 * SB + 256 + 64 + std::max(lp.small_maxm, 1)), st,
                              static_cast<const SolveTask*>(F.stasks) + lp.small_begin, F.rlist, F.L, F.Linv, xp);
-        else
-          hipLaunchKernelGGL(k_solve_bwd<false>, dim3(lp.small_cnt), dim3(256),
-                             sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,
-                             F.smallnodes + lp.small_begin, F.rlist, F.gperm, F.L, xp);
+        else {
+          const SolveTask* stk = static_cast<const SolveTask*>(F.stasks) + lp.small_begin;
+          if (lp.small_cnt > lp.tiny_cnt)
+            hipLaunchKernelGGL(k_solve_bwd<false>, dim3(lp.small_cnt - lp.tiny_cnt), dim3(256),
+                               sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,
+                               F.smallnodes + lp.small_begin + lp.tiny_cnt, F.rlist, F.gperm, F.L, xp);
+          if (lp.tiny_cnt > 0)
+            hipLaunchKernelGGL(k_solve_bwd_tiny, dim3((lp.tiny_cnt + 3) / 4), dim3(256), 0, st, stk, lp.tiny_cnt,
+                               F.rlist, F.gperm, F.L, xp);
+        }
       }
     }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));

@@ -42,10 +42,12 @@ struct BigStep {
 
 struct LevelPlan {
   int node_begin, node_end;                 // range in lvlnodes
+  std::vector<int> panel_rows;              // per step: tallest panel (rows, <= 128) among the step's diag tasks
   std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
   int tile_begin, tile_cnt;                 // range in the TileTask array
   int pull_begin, pull_cnt;                 // extend-add tasks of the level (k_assemble_pull)
   int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
+  int tiny_cnt;                             // ... of which the first tiny_cnt are tiny (n <= 64, m - n <= 64)
   int big_begin, big_cnt;                                // solve: blocked multi-launch fronts
   std::vector<BigStep> bigsteps;
 };
