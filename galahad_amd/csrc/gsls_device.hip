@@ -506,7 +506,8 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   const int fw = blockIdx.x & 3;
   if (wave == fw) fact16(0);
   __syncthreads();
-  for (int jb = 0; jb < NB; jb += 16) {
+  const int wup = LDL ? ((w + 15) & ~15) : NB;   // LDL: stages beyond the front's last column are pure padding
+  for (int jb = 0; jb < wup; jb += 16) {
     STAMP(4 + 3 * (jb >> 4));
     // ---- b. rows below: Y = R * L16^-T [* D16^-1], computed transposed so that lanes run along the rows
     // of P.  Three row tiles per wave, no branches around the MFMAs: a tile index past the end is
@@ -554,7 +555,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     }
     __syncthreads();
     STAMP(5 + 3 * (jb >> 4));
-    if (jb + 16 < NB) {
+    if (jb + 16 < wup) {
       const double* dsc = LDL ? YP : nullptr;
       // ---- c1. the next block column only, all waves ------------------------------------------------
       const int cj1 = (jb >> 4) + 1;
@@ -1200,6 +1201,65 @@ k_contrib(const NodeDesc* __restrict__ nodes, const TileTask* __restrict__ tasks
         const int col = t.tj * TS + wc + 16 * j + lq + 4 * r;
         if (row < cm && col < cm && row >= col) Cb[int64_t(col) * cm + row] = cv[i][j][r] - acc[i][j][r];
       }
+}
+
+// Tiny contribution blocks ((m-n) <= 16, n <= 64): one WAVE per front, two fronts per workgroup.  A
+// 64 x 64 MFMA tile per such front wasted 15/16 of its work; here L21 and L21*D sit in LDS and every
+// lane owns up to four entries of C.
+struct TinyContribTask {
+  int32_t n, cm, ld, sptr;
+  int64_t loff, coff;
+};
+template <bool POSDEF>
+__global__ void __launch_bounds__(128)
+k_contrib_tiny(const TinyContribTask* __restrict__ tasks, int ntask, const double* __restrict__ L,
+               const double* __restrict__ D, double* __restrict__ C) {
+  __shared__ double Ls[2][16 * 65], LDs[2][16 * 65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ti = blockIdx.x * 2 + wave;
+  if (ti >= ntask) return;
+  const TinyContribTask t = tasks[ti];
+  const int n = t.n, cm = t.cm;
+  const double* Lb = L + t.loff;
+  const double* dinv = D + 2 * int64_t(t.sptr);
+  double* ls = Ls[wave];
+  double* lds = LDs[wave];
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {            // row i of L21, columns kq, kq+4, ...
+    const int k = kq + 4 * u;
+    const bool ok = (i < cm && k < n);
+    const double v = ok ? Lb[int64_t(k) * t.ld + n + i] : 0.0;
+    double ld = v;
+    if (!POSDEF && ok) {                    // (L D)(i,k): D held inverted, calc_ld.hxx:43-118
+      const double d0 = dinv[2 * k], d1 = dinv[2 * k + 1];
+      if (isinf(d0)) {                      // second column of a 2x2 pivot
+        const double d11 = dinv[2 * k - 2], d21 = dinv[2 * k - 1], d22 = d1;
+        const double a1 = Lb[int64_t(k - 1) * t.ld + n + i];
+        ld = (-d21 * a1 + d11 * v) / (d11 * d22 - d21 * d21);
+      } else if (isinf(dinv[2 * k + 2])) {  // first column
+        const double d22 = dinv[2 * k + 3];
+        const double a2 = Lb[int64_t(k + 1) * t.ld + n + i];
+        ld = (d22 * v - d1 * a2) / (d0 * d22 - d1 * d1);
+      } else {
+        ld = (d0 != 0.0) ? v / d0 : 0.0;
+      }
+    }
+    ls[i * 65 + k] = v;
+    lds[i * 65 + k] = ld;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  double* Cb = C + t.coff;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = kq + 4 * u;               // entry (i, j), i >= j
+    if (i < cm && j <= i) {
+      double acc = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) acc = fma(ls[i * 65 + k], lds[j * 65 + k], acc);
+      Cb[int64_t(j) * cm + i] -= acc;
+    }
+  }
 }
 
 // =================================================================================================
@@ -1971,7 +2031,7 @@ extern "C" void gsls_debug_stamps(unsigned long long* out) {
 #endif
 
 void dev_free(DeviceFactor& F) {
-  void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.asrc, F.adst, F.arow,
+  void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.fastok, F.hint, F.segC, F.segV, F.posowner};
@@ -2038,6 +2098,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<PanelTask> pt;
   std::vector<TileTask> tt;
   std::vector<PullSeg> psg;
+  std::vector<TinyContribTask> tct;
   std::vector<PullTask> ptk;
   std::vector<int32_t> smalln, bign;
   std::vector<BigTrsv> btr;
@@ -2081,15 +2142,21 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       lp.panel_cnt[2 * st_ + 1] = int(pt.size()) - lp.panel_begin[2 * st_ + 1];
     }
     lp.tile_begin = int(tt.size());
+    lp.tinyc_begin = int(tct.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
       const int s = lvl_nodes[i];
       if (S.sparent[s] >= nn) continue;  // roots have no (used) contribution block
       const int cm = S.nrow(s) - S.ncol(s);
+      if (cm <= 16 && S.ncol(s) <= 64) {   // tiny: a wave per front (k_contrib_tiny)
+        if (cm > 0) tct.push_back(TinyContribTask{S.ncol(s), cm, S.ldl[s], S.sptr[s], S.loff[s], S.coff[s]});
+        continue;
+      }
       const int nt = (cm + TS - 1) / TS;
       for (int tj = 0; tj < nt; ++tj)
         for (int ti = tj; ti < nt; ++ti) tt.push_back(TileTask{s, ti, tj, 0});
     }
     lp.tile_cnt = int(tt.size()) - lp.tile_begin;
+    lp.tinyc_cnt = int(tct.size()) - lp.tinyc_begin;
     // extend-add: one pull task per PCOLS columns of every parent, children in clist order
     lp.pull_begin = int(ptk.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
@@ -2246,6 +2313,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     HIPCHK(upload(d2, ptk, st));
     F.pullsegs = d1;
     F.pulltasks = d2;
+    TinyContribTask* d3 = nullptr;
+    HIPCHK(upload(d3, tct, st));
+    F.tinyctasks = d3;
   }
   HIPCHK(upload(F.asrc, asrc, st));
   HIPCHK(upload(F.adst, adst, st));
@@ -2324,6 +2394,10 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
     if (lp.tile_cnt > 0)
       hipLaunchKernelGGL(k_contrib<POSDEF>, dim3(lp.tile_cnt), dim3(256), 0, st, F.nodes,
                          F.ttasks + lp.tile_begin, F.L, F.D, F.C);
+    if (lp.tinyc_cnt > 0)
+      hipLaunchKernelGGL(k_contrib_tiny<POSDEF>, dim3((lp.tinyc_cnt + 1) / 2), dim3(128), 0, st,
+                         static_cast<const TinyContribTask*>(F.tinyctasks) + lp.tinyc_begin, lp.tinyc_cnt, F.L, F.D,
+                         F.C);
   }
   return hipGetLastError();
 }

@@ -45,6 +45,7 @@ struct LevelPlan {
   std::vector<int> panel_rows;              // per step: tallest panel (rows, <= 128) among the step's diag tasks
   std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
   int tile_begin, tile_cnt;                 // range in the TileTask array
+  int tinyc_begin, tinyc_cnt;               // fronts with a tiny contribution block (k_contrib_tiny)
   int pull_begin, pull_cnt;                 // extend-add tasks of the level (k_assemble_pull)
   int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
   int tiny_cnt;                             // ... of which the first tiny_cnt are tiny (n <= 64, m - n <= 64)
@@ -61,6 +62,7 @@ struct DeviceFactor {
   int32_t* lvlnodes = nullptr;
   void* pullsegs = nullptr;        // extend-add: PullSeg / PullTask lists (gsls_device.hip)
   void* pulltasks = nullptr;
+  void* tinyctasks = nullptr;
   int32_t* smallnodes = nullptr;
   void* stasks = nullptr;          // SolveTask per entry of smallnodes (same indexing)
   int32_t* bignodes = nullptr;
