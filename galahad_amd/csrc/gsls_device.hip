@@ -322,10 +322,21 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   const int ldq = LDL ? ldq_arg : LDQ;
   const int nrt = LDL ? nrt_arg : PRX / 16;       // row tiles: the identity rows (W) only for Cholesky
   double* YP = P + NB * ldq;                        // LDL: [16][ldq], Y' = R L16^-T of the current stage
-  __shared__ double Xs[16 * 16];                    // Xs[k][n] = (L16^-1)[n][k]
-  __shared__ double Zs[16 * 16];                    // LDL: Zs[k][n] = (D16^-1 L16^-1)[n][k]
-  __shared__ double dgs[2 * NB + 4];                // LDL: inverted pivots in the layout of D
-  __shared__ int32_t s_neg, s_two;
+  // LDL scratch lives in tiles of P ABOVE the diagonal, which the factorization never touches (LDS is what
+  // limits the number of small fronts per CU): Zs[k][n] = (D16^-1 L16^-1)[n][k] in rows 0..15 of columns
+  // 48..63, the inverted pivots (layout of D, 128 doubles) in rows 0..15 of columns 32..39
+  double* Zs = P + 48 * ldq;
+  double* dgp = P + 32 * ldq;
+  auto dgs = [&](int i) -> double& { return dgp[(i >> 4) * ldq + (i & 15)]; };
+  int negacc = 0, twoacc = 0;                       // LDL: inertia counts, live in the serial-stage wave
+  // Xs[k][n] = (L16^-1)[n][k]: LDL keeps it in rows 0..15 of YP, which no stage ever uses (LDS is what
+  // limits the number of small fronts per CU)
+  double* Xs = YP;
+  const int xst = LDL ? ldq : 16;
+  if constexpr (!LDL) {
+    __shared__ double XsC[16 * 16];
+    Xs = XsC;
+  }
 
   const PanelTask t = tasks[blockIdx.x];
   const NodeDesc nd = nodes[t.node];
@@ -390,7 +401,6 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       const int k = e & 63, n = e >> 6;
       P[n * ldq + PR + k] = (k == n) ? 1.0 : 0.0;
     }
-  if (tid == 0) { s_neg = 0; s_two = 0; }
   __syncthreads();
   STAMP(2);
 
@@ -441,7 +451,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         if (det < 0.0) nneg += 1;
         else if (a11 + a22 < 0.0) nneg += 2;
         ++ntwo;
-        if (lane == 0) { dgs[2 * (jb + j)] = d11; dgs[2 * (jb + j) + 1] = d21; dgs[2 * (jb + j) + 2] = INFINITY; dgs[2 * (jb + j) + 3] = d22; }
+        if (lane == 0) { dgs(2 * (jb + j)) = d11; dgs(2 * (jb + j) + 1) = d21; dgs(2 * (jb + j) + 2) = INFINITY; dgs(2 * (jb + j) + 3) = d22; }
         second = true;
         continue;
       }
@@ -457,7 +467,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         rd = fma(fma(-d, rd, 1.0), rd, rd);
         own = v[j] * rd;                             // L rows: l_rj (lane j: 1); identity lanes: x_j / d
         if (lane < 16 && lr > j && !(fabs(own) <= inv_u)) { bad = true; why |= 2; }   // threshold test inside the block
-        if (lane == 0) { dgs[2 * (jb + j)] = rd; dgs[2 * (jb + j) + 1] = 0.0; }
+        if (lane == 0) { dgs(2 * (jb + j)) = rd; dgs(2 * (jb + j) + 1) = 0.0; }
       } else {
         if (!(d > 0.0)) failj = min(failj, j);
         double y = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware estimate + two Newton steps
@@ -477,27 +487,27 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       if (LDL && lane < 16) v[j] = own;              // the identity lanes keep x_j
     }
     if (!LDL && lane == 0 && failj < 16 && jb + failj < w) atomicMin(&stat[0], nd.sptr + kb + jb + failj);
-    if (LDL && lane == 0) { s_neg += nneg; s_two += ntwo; }   // only one wave ever runs this
+    if (LDL) { negacc += nneg; twoacc += ntwo; }
     if (lane < 16) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) P[(jb + k) * ldq + jb + lr] = (k <= lr) ? v[k] : 0.0;
     } else if (lane < 32) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) Xs[lr * 16 + k] = (k >= lr) ? v[k] : 0.0;
+      for (int k = 0; k < 16; ++k) Xs[lr * xst + k] = (k >= lr) ? v[k] : 0.0;
       if (LDL) {   // Z = D16^-1 L16^-1, column lr; the pivots come back from LDS (dgs, written by lane 0)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         double z[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) z[k] = dgs[2 * (jb + k)] * v[k];
+        for (int k = 0; k < 16; ++k) z[k] = dgs(2 * (jb + k)) * v[k];
 #pragma unroll
         for (int k = 0; k + 1 < 16; ++k)
-          if (isinf(dgs[2 * (jb + k) + 2])) {        // 2x2 pivot at (k, k+1): [d11, d21, inf, d22]
-            const double d11 = dgs[2 * (jb + k)], d21 = dgs[2 * (jb + k) + 1], d22 = dgs[2 * (jb + k) + 3];
+          if (jb + k + 1 < NB && isinf(dgs(2 * (jb + k) + 2))) {   // 2x2 pivot at (k, k+1): [d11, d21, inf, d22]
+            const double d11 = dgs(2 * (jb + k)), d21 = dgs(2 * (jb + k) + 1), d22 = dgs(2 * (jb + k) + 3);
             z[k] = d11 * v[k] + d21 * v[k + 1];
             z[k + 1] = d21 * v[k] + d22 * v[k + 1];
           }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Zs[lr * 16 + k] = z[k];
+        for (int k = 0; k < 16; ++k) Zs[lr * ldq + k] = z[k];
       }
     }
   };
@@ -519,8 +529,8 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       int rtc[3];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        xa[k] = Xs[(4 * k + lq) * 16 + lr];                  // A[i=n][k] = X[n][k]
-        za[k] = LDL ? Zs[(4 * k + lq) * 16 + lr] : 0.0;
+        xa[k] = Xs[(4 * k + lq) * xst + lr];                 // A[i=n][k] = X[n][k]
+        za[k] = LDL ? Zs[(4 * k + lq) * ldq + lr] : 0.0;
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -585,11 +595,13 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     }
     if (anybad) return;                              // k_diag_ldlt takes the block from the untouched input
     if (tid < w) {
-      D[2 * int64_t(nd.sptr + kb + tid)] = dgs[2 * tid];
-      D[2 * int64_t(nd.sptr + kb + tid) + 1] = dgs[2 * tid + 1];
+      D[2 * int64_t(nd.sptr + kb + tid)] = dgs(2 * tid);
+      D[2 * int64_t(nd.sptr + kb + tid) + 1] = dgs(2 * tid + 1);
     }
-    if (tid == 0 && s_neg) atomicAdd(&stat[2], s_neg);
-    if (tid == 0 && s_two) atomicAdd(&stat[3], s_two);
+    if (wave == fw && lane == 0) {
+      if (negacc) atomicAdd(&stat[2], negacc);
+      if (twoacc) atomicAdd(&stat[3], twoacc);
+    }
   }
   // ---- store L (lower trapezoid) and W = L11^-T; both coalesced along rows ---------------------------
   {
@@ -707,12 +719,19 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     int bi = INT_MAX;
     {
       const int rr = p + (tid & 63);
-      if (rr < w)
-        for (int c = p + (tid >> 6); c <= rr; c += 4) {
-          const double v = fabs(P[c * LDP + rr]);
-          const int id = c * 64 + rr;
-          if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
+      if (rr < w) {
+        double cand[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int c = p + (tid >> 6) + 4 * q;
+          cand[q] = (c <= rr) ? fabs(P[c * LDP + rr]) : -2.0;
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int id = (p + (tid >> 6) + 4 * q) * 64 + rr;
+          if (cand[q] > bv || (cand[q] == bv && id < bi)) { bv = cand[q]; bi = id; }
+        }
+      }
     }
     for (int o = 32; o > 0; o >>= 1) {
       const double ov = __shfl_down(bv, o);
@@ -770,8 +789,23 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       if (kofs == 0 && r > p && r < pr) w1[r] = P[p * LDP + r];
       __syncthreads();
       const double l = (r > p && r < pr) ? w1[r] * d11 : 0.0;
-      for (int c = p + 1 + kofs; c < w; c += 2)
-        if (r >= c && r < pr) P[c * LDP + r] -= l * w1[c];
+      // rank-1 update of this thread's row, every second column: operands into registers first (the
+      // compiler cannot reorder LDS loads across the stores)
+      for (int c0 = p + 1 + kofs; c0 < w; c0 += 32) {
+        double pv[16], wv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int c = c0 + 2 * q;
+          const bool ok = (c < w && r >= c && r < pr);
+          pv[q] = ok ? P[c * LDP + r] : 0.0;
+          wv[q] = ok ? w1[c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int c = c0 + 2 * q;
+          if (c < w && r >= c && r < pr) P[c * LDP + r] = pv[q] - l * wv[q];
+        }
+      }
       if (kofs == 0) {
         if (r > p && r < pr) {
           P[p * LDP + r] = l;
@@ -793,8 +827,22 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       __syncthreads();
       double l1 = 0.0, l2 = 0.0;
       if (r > p + 1 && r < pr) { l1 = d11 * w1[r] + d21 * w2[r]; l2 = d21 * w1[r] + d22 * w2[r]; }
-      for (int c = p + 2 + kofs; c < w; c += 2)
-        if (r >= c && r < pr) P[c * LDP + r] -= w1[c] * l1 + w2[c] * l2;
+      for (int c0 = p + 2 + kofs; c0 < w; c0 += 32) {
+        double pv[16], wv1[16], wv2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int c = c0 + 2 * q;
+          const bool ok = (c < w && r >= c && r < pr);
+          pv[q] = ok ? P[c * LDP + r] : 0.0;
+          wv1[q] = ok ? w1[c] : 0.0;
+          wv2[q] = ok ? w2[c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int c = c0 + 2 * q;
+          if (c < w && r >= c && r < pr) P[c * LDP + r] = pv[q] - (wv1[q] * l1 + wv2[q] * l2);
+        }
+      }
       if (kofs == 0) {
         if (r > p + 1 && r < pr) {
           P[p * LDP + r] = l1;

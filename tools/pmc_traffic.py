@@ -1,0 +1,37 @@
+"""Sum the FETCH_SIZE / WRITE_SIZE counters (two rocprofv3 --pmc passes) over the kernels of the LAST
+bench step: the solve sweep (k_permute_in .. k_permute_out) and the factorization (k_iota .. before
+k_permute_in).  FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide coalesced reads at
+64 B, MI355X_MICROARCH.md); both counters are in KB."""
+import csv, glob, json, sys
+
+
+def load(d):
+    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    return rows
+
+
+def split(rows):
+    names = [r['Kernel_Name'] for r in rows]
+    pin = max(i for i, n in enumerate(names) if 'k_permute_in' in n)
+    pout = max(i for i, n in enumerate(names) if 'k_permute_out' in n)
+    iota = max(i for i, n in enumerate(names) if 'k_iota' in n and i < pin)
+    return rows[iota:pin], rows[pin:pout + 1]
+
+
+def total(rows):
+    return sum(float(r['Counter_Value']) for r in rows)
+
+
+fr, wr = load(sys.argv[1]), load(sys.argv[2])
+ff, fs = split(fr)
+wf, ws = split(wr)
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, each with --kernel-trace only), "
+               "bench.py --steps 2 --warmup 1 (%s); last step only; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+               "(gfx950 tallies 128-B requests of wide coalesced reads at 64 B); units KB*1024" % sys.argv[3],
+       "solve_sweep": {"fetch_kb_raw": total(fs), "write_kb": total(ws), "launches": len(fs),
+                       "hbm_bytes_corrected": int((2 * total(fs) + total(ws)) * 1024)},
+       "factorize": {"fetch_kb_raw": total(ff), "write_kb": total(wf), "launches": len(ff),
+                     "hbm_bytes_corrected": int((2 * total(ff) + total(wf)) * 1024)}}
+print(json.dumps(out, indent=1))
