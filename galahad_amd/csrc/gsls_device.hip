@@ -29,9 +29,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #ifdef GSLS_STAMPS   // diagnostic build only: in-kernel phase stamps (s_memtime), never in the product
 __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PH(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); phacc[k] += t__ - pht; pht = t__; } while (0)
 #define STAMPN(i) do { __syncthreads(); if (threadIdx.x == 0 && nd.m > 300 && nd.n > 100 && nd.m > nd.n) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define PH(k) do {} while (0)
 #define STAMPN(i) do {} while (0)
 #endif
 
@@ -713,7 +715,12 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   int fail_from = NB; // uniform: columns [fail_from, w) of the block could not be eliminated here
   int bigcol = NB;    // per thread: first column with an |l| above 1/u below the block
   int p = 0;
+#ifdef GSLS_STAMPS
+  unsigned long long phacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pht = __builtin_amdgcn_s_memtime();
+  const unsigned long long ph0 = pht;
+#endif
   while (p < w) {
+    PH(7);
     // ---- largest remaining entry of the block (lower triangle, rows/cols p..w-1) ----
     double bv = -1.0;
     int bi = INT_MAX;
@@ -738,8 +745,10 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       const int oi = __shfl_down(bi, o);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
+    PH(0);
     if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
     __syncthreads();
+    PH(1);
     bv = rv[0]; bi = ri[0];
 #pragma unroll
     for (int k = 1; k < 4; ++k)
@@ -780,14 +789,18 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         mcol = trow;
       }
     }
+    PH(2);
     __syncthreads();   // every thread has read the candidates
+    PH(3);
     if (pivsiz == 0) { nfail += w - p; fail_from = p; break; }
     if (pivsiz == 1) {
       swap_sym(P, lperm, pr, p, trow, tid);
       __syncthreads();
+      PH(4);
       const double d11 = 1.0 / a11;
       if (kofs == 0 && r > p && r < pr) w1[r] = P[p * LDP + r];
       __syncthreads();
+      PH(5);
       const double l = (r > p && r < pr) ? w1[r] * d11 : 0.0;
       // rank-1 update of this thread's row, every second column: operands into registers first (the
       // compiler cannot reorder LDS loads across the stores)
@@ -814,6 +827,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
         if (r == p) { P[p * LDP + p] = 1.0; dg[2 * p] = d11; dg[2 * p + 1] = 0.0; }
       }
       __syncthreads();
+      PH(6);
       p += 1;
     } else {
       swap_sym(P, lperm, pr, p, mcol, tid);
@@ -859,6 +873,9 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
     }
   }
   __syncthreads();
+#ifdef GSLS_STAMPS
+  if (tid == 0) { for (int q = 0; q < 8; ++q) g_stamps[40 + q] = phacc[q]; g_stamps[48] = pht - ph0; }
+#endif
   // first column that failed the a-posteriori test (min over the workgroup, via LDS)
   __shared__ int32_t s_bigcol;
   if (tid == 0) s_bigcol = NB;

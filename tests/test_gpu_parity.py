@@ -333,3 +333,51 @@ def test_full_size_cfg2_properties():
     s.factorize(m, c, i)
     assert np.array_equal(s.solve(m, rhs, c, i), x)      # deterministic: no atomics in the path
     s.terminate()
+
+
+@pytest.mark.parametrize("case", ["kkt", "grid_indef", "rand_indef", "kkt_perm_reversed"])
+def test_refactorization_after_learning(case):
+    """The handle learns from its first pivoted factorization (order repair, in-block pivot sequence,
+    2x2 positions) and later factorizations run the optimistic LDL^T kernel with the complete-pivoting
+    kernel as fallback.  Refactorizing the same values, and then values that drift as in an
+    interior-point loop, must keep the inertia and the residual; against the oracle on the same matrix."""
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    rng = np.random.default_rng(11)
+    perm = None
+    if case == "kkt":
+        prob = P.kkt_qpband(6000, 1200, seed=5)
+    elif case == "kkt_perm_reversed":
+        prob = P.kkt_qpband(500, 140, seed=6)
+        perm = np.arange(prob[0], 0, -1)          # constraints first: zero pivots everywhere
+    elif case == "grid_indef":
+        prob = P.grid2d(50, 40, shift=1.0)
+    else:
+        prob = P.random_sparse(3000, 5, seed=9, spd=False)
+    n, row, col, val, rhs, xs = prob
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val.copy())
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    c.pivot_control = 1
+    s.analyse(m, c, i, PERM=perm)
+    assert i.status == 0
+    diag = np.where(row == col)[0]
+    neg_ref = None
+    for it in range(4):
+        if it >= 2:   # drift the diagonal like barrier terms do (keeps the zero block of a KKT matrix zero)
+            nzd = diag[np.abs(m.val[diag]) > 0]
+            m.val[nzd] *= 10.0 ** rng.uniform(-0.3, 0.3, len(nzd))
+        s.factorize(m, c, i)
+        assert i.status == 0, (it, i.gsls_inform)
+        b = P.sym_matvec(n, row - 1, col - 1, m.val, xs)
+        x = s.solve(m, b, c, i)
+        assert P.scaled_residual(n, row, col, m.val, x, b) <= 1e-10, it
+        if it < 2:
+            if neg_ref is None:
+                neg_ref = i.negative_eigenvalues
+                dense = np.zeros((n, n)) if n <= 700 else None
+                if dense is not None:
+                    dense[row - 1, col - 1] = m.val
+                    dense = dense + np.tril(dense, -1).T
+                    assert neg_ref == int((np.linalg.eigvalsh(dense) < 0).sum())
+            assert i.negative_eigenvalues == neg_ref      # same matrix: same inertia, whichever kernel ran
+    s.terminate()
