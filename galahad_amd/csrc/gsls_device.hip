@@ -1606,6 +1606,7 @@ struct SolveTask {
   int64_t loff, roff, moff;
   int32_t iblk, cbeg, cend, ccm0, ccm1, pad;
   int64_t cmoff0, cmoff1;
+  int64_t goff;      // first entry of the front's rows in the gather lists (gth_ptr)
 };
 
 // rows [i] x columns [b, b+nb) of a front, one row per thread, every load issued before any use
@@ -1796,10 +1797,9 @@ k_solve_bwd_chol(const SolveTask* __restrict__ tasks, const int32_t* __restrict_
 constexpr int TINY_M = 128;
 
 __global__ void __launch_bounds__(256)
-k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const NodeDesc* __restrict__ nodes,
-                 const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
-                 const int32_t* __restrict__ gperm, const double* __restrict__ L,
-                 double* __restrict__ xp, double* __restrict__ cvec) {
+k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* __restrict__ gth_ptr,
+                 const int64_t* __restrict__ gth_src, const int32_t* __restrict__ gperm,
+                 const double* __restrict__ L, double* __restrict__ xp, double* __restrict__ cvec) {
   __shared__ double rsh[4][TINY_M];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ti = blockIdx.x * 4 + wave;
@@ -1815,15 +1815,14 @@ k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const NodeDesc*
 #pragma unroll
   for (int k = 0; k < 64; ++k) low[k] = (lane < cm && k < n) ? Lb[int64_t(k) * nd.ld + n + lane] : 0.0;
   const int pslot = (lane < n) ? gperm[nd.sptr + lane] - nd.sptr : 0;   // pivot `lane` sits at this analyse position
-  for (int i = lane; i < m; i += 64) r[i] = (i < n) ? xp[nd.sptr + i] : 0.0;
-  for (int ci = nd.cbeg; ci < nd.cend; ++ci) {   // children in order; a child's targets are distinct
-    int64_t moff;
-    int ccm;
-    if (ci == nd.cbeg) { moff = nd.cmoff0; ccm = nd.ccm0; }
-    else if (ci == nd.cbeg + 1) { moff = nd.cmoff1; ccm = nd.ccm1; }
-    else { const NodeDesc cn = nodes[clist[ci]]; moff = cn.moff; ccm = cn.m - cn.n; }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (int i = lane; i < ccm; i += 64) r[cmap[moff + i]] += cvec[moff + i];
+  // right-hand side + the children's contribution vectors: every row of the front PULLS its sources in
+  // child order (host-built gather lists: fixed summation order, and a front with hundreds of children
+  // costs one round trip, not one per child)
+  for (int i = lane; i < m; i += 64) {
+    double acc0 = (i < n) ? xp[nd.sptr + i] : 0.0;
+    const int g0 = gth_ptr[nd.goff + i], g1 = gth_ptr[nd.goff + i + 1];
+    for (int g = g0; g < g1; ++g) acc0 += cvec[gth_src[g]];
+    r[i] = acc0;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   double yv = (lane < n) ? r[pslot] : 0.0;
@@ -2099,7 +2098,7 @@ void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.fastok, F.hint, F.segC, F.segV, F.posowner};
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.segC, F.segV, F.posowner};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -2333,6 +2332,28 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         t.cmoff1 = S.cmapptr[c];
       }
     }
+    // gather lists: for every row of a small front, the children's contribution-vector entries that add
+    // into it, in child order
+    std::vector<int32_t> gptr;
+    std::vector<int64_t> gsrc;
+    gptr.push_back(0);
+    for (size_t i = 0; i < smalln.size(); ++i) {
+      const int sn = smalln[i];
+      const int pm = S.nrow(sn);
+      stv[i].goff = int64_t(gptr.size()) - 1;
+      std::vector<std::vector<int64_t>> rows(pm);
+      for (int ci = S.cptr[sn]; ci < S.cptr[sn + 1]; ++ci) {
+        const int c = S.clist[ci];
+        const int ccm = S.nrow(c) - S.ncol(c);
+        for (int k = 0; k < ccm; ++k) rows[S.cmap[S.cmapptr[c] + k]].push_back(S.cmapptr[c] + k);
+      }
+      for (int r2 = 0; r2 < pm; ++r2) {
+        gsrc.insert(gsrc.end(), rows[r2].begin(), rows[r2].end());
+        gptr.push_back(int32_t(gsrc.size()));
+      }
+    }
+    HIPCHK(upload(F.gth_ptr, gptr, st));
+    HIPCHK(upload(F.gth_src, gsrc, st));
     SolveTask* d = nullptr;
     HIPCHK(upload(d, stv, st));
     F.stasks = d;
@@ -2517,7 +2538,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
           const SolveTask* stk = static_cast<const SolveTask*>(F.stasks) + lp.small_begin;
           if (lp.tiny_cnt > 0)
             hipLaunchKernelGGL(k_solve_fwd_tiny, dim3((lp.tiny_cnt + 3) / 4), dim3(256), 0, st, stk, lp.tiny_cnt,
-                               F.nodes, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+                               F.gth_ptr, F.gth_src, F.gperm, F.L, xp, F.cvec);
           if (lp.small_cnt > lp.tiny_cnt)
             hipLaunchKernelGGL(k_solve_fwd<false>, dim3(lp.small_cnt - lp.tiny_cnt), dim3(256),
                                sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,

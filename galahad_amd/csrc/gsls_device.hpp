@@ -65,6 +65,8 @@ struct DeviceFactor {
   void* tinyctasks = nullptr;
   int32_t* smallnodes = nullptr;
   void* stasks = nullptr;          // SolveTask per entry of smallnodes (same indexing)
+  int32_t* gth_ptr = nullptr;      // forward solve: per row of every small front, range in gth_src
+  int64_t* gth_src = nullptr;      // ... the cvec entries (children's contributions) that add into the row
   int32_t* bignodes = nullptr;
   void* bigtrsv = nullptr;
   void* biggemv = nullptr;
