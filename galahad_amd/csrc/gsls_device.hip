@@ -721,10 +721,23 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 #endif
   while (p < w) {
     PH(7);
-    // ---- largest remaining entry of the block (lower triangle, rows/cols p..w-1) ----
+    // ---- the next pivot in the given order first: accepted as a 1x1 if it passes the threshold test
+    // against its whole column (|a_rp| <= |a_pp| / u for every row below, ldlt_app.cxx:303-321) -- one LDS
+    // read per thread and one barrier instead of the block-wide search below
     double bv = -1.0;
     int bi = INT_MAX;
+    bool natural = false;
     {
+      const double app = P[p * LDP + p];
+      bool viol = !(fabs(app) >= small);
+      if (kofs == 0 && r > p && r < pr) viol |= !(fabs(P[p * LDP + r]) <= fabs(app) * inv_u);
+      natural = !__syncthreads_or(viol);
+      if (natural) { bv = fabs(app); bi = p * 64 + p; }
+    }
+    PH(7);
+    // ---- otherwise the largest remaining entry of the block (lower triangle, rows/cols p..w-1) ----
+    if (!natural) {
+      {
       const int rr = p + (tid & 63);
       if (rr < w) {
         double cand[16];
@@ -753,6 +766,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 #pragma unroll
     for (int k = 1; k < 4; ++k)
       if (rv[k] > bv || (rv[k] == bv && ri[k] < bi)) { bv = rv[k]; bi = ri[k]; }
+    }
 
     if (!(bv >= small)) {
       // nothing usable left in the block: zero pivots if the rows below are negligible as well
