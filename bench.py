@@ -177,6 +177,10 @@ def main():
         if tsh is not None:
             st = tsh.factorize_dev(d_val, posdef)
             assert st["flag"] >= 0, st
+            ginf.num_factor, ginf.num_flops = st["num_factor"], st["num_flops"]
+            ginf.nlevels, ginf.num_sup = st["nlevels"], st["num_sup"]
+            ginf.num_neg, ginf.num_two = st["num_neg"], st["num_two"]
+            ginf.num_delay = max(ginf.num_delay, st["num_delay"])
             d_x.copy_(d_rhs)
             tsh.solve_dev(d_x)
             return

@@ -147,7 +147,9 @@ class TreeShardedSLS:
         self._host_reduce(stats, self.dist.ReduceOp.SUM)
         warn = self._total(max(flags), self.dist.ReduceOp.MAX)
         return {"flag": int(warn), "num_neg": int(stats[0].item()), "num_two": int(stats[1].item()),
-                "matrix_rank": self.n - int(stats[2].item()), "num_delay": moved}
+                "matrix_rank": self.n - int(stats[2].item()), "num_delay": moved,
+                "num_factor": inf.num_factor, "num_flops": inf.num_flops, "nlevels": inf.nlevels,
+                "num_sup": inf.num_sup}
 
     def _host_reduce(self, t, op):
         if self.direct:
