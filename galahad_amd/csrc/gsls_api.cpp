@@ -27,6 +27,9 @@ struct Handle {
   DeviceFactor F;
   bool analysed = false, factored = false, posdef = false, dev_ready = false, have_scale = false;
   int learned = 0;            // rounds of folding the in-block pivot sequence of a pivoted factorization into the order
+  bool tiny_ready = false;    // the order is learned: tiny fronts may go through the wave-per-front kernel
+  int tiny_strikes = 0;       // factorizations in which that kernel met a pivot it could not take
+  std::vector<int> tiny_black;   // tiny fronts that kernel gave up on: they stay on the workgroup path
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -199,6 +202,9 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
   const double t0 = now();
   h->analysed = h->factored = h->dev_ready = false;
   h->learned = 0;
+  h->tiny_ready = false;
+  h->tiny_strikes = 0;
+  h->tiny_black.clear();
   if (n < 0) return inform->flag = GSLS_ERROR_A_N_OOR;
   if (n > 0 && (!ptr || !row)) return inform->flag = GSLS_ERROR_A_PTR;
   if (n > 0 && ptr[0] != 1) return inform->flag = GSLS_ERROR_A_PTR;
@@ -300,16 +306,42 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   h->have_scale = (scale != nullptr);
   int32_t st[16];
   int total_moved = 0;
+  bool tiny_off = false;
+  int tiny_repeats = 0;
   const int max_pass = 200;
   for (int pass = 0;; ++pass) {
-    e = dev_factor(h->S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream);
+    // refactorizations of a learned order: tiny fronts whole, a wave each (k_front_tiny); if that kernel
+    // meets a pivot it cannot take (stat[13]) the pass is repeated on the workgroup path
+    const bool use_tiny = !posdef && !scale && h->tiny_ready && !tiny_off;
+    e = dev_factor(h->S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream, use_tiny);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     e = hipMemcpyAsync(st, F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
+    if (use_tiny && st[13] > 0) {
+      // fronts the wave-per-front kernel gave up on join the blacklist (they take the workgroup kernels from
+      // now on, a short extra task list per level) and the pass is repeated
+      const int nf = std::min<int>(st[13], FAILCAP);
+      std::vector<int32_t> nodes(nf);
+      e = hipMemcpy(nodes.data(), F.tinyfail, nf * sizeof(int32_t), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      h->tiny_black.insert(h->tiny_black.end(), nodes.begin(), nodes.end());
+      std::sort(h->tiny_black.begin(), h->tiny_black.end());
+      h->tiny_black.erase(std::unique(h->tiny_black.begin(), h->tiny_black.end()), h->tiny_black.end());
+      if (getenv("GSLS_DEBUG"))
+        fprintf(stderr, "[gsls] pass %d: %d tiny fronts need pivoting (blacklist %zu), repeating\n", pass, st[13], h->tiny_black.size());
+      if (++tiny_repeats > 4 || st[13] > FAILCAP || h->tiny_black.size() * 10 > size_t(h->S.nnodes)) {
+        tiny_off = true;                         // not a pattern for that kernel
+        if (++h->tiny_strikes >= 3) h->tiny_ready = false;
+      } else {
+        e = dev_set_tiny_blacklist(h->S, F, h->tiny_black, h->stream);
+        if (e != hipSuccess) return fail_hip(h, inform, e);
+      }
+      continue;
+    }
     if (getenv("GSLS_DEBUG"))
-      fprintf(stderr, "[gsls] pass %d: blocks fast %d, pivoted %d, failed columns %d, 2x2 %d | why: small %d inblock %d straddle %d rej2x2 %d below %d\n", pass, st[6], st[7], st[4], st[3], st[8], st[9], st[10], st[11], st[12]);
+      fprintf(stderr, "[gsls] pass %d (tiny %d ready %d strikes %d): blocks fast %d, pivoted %d, failed columns %d, 2x2 %d | why: small %d inblock %d straddle %d rej2x2 %d below %d\n", pass, int(use_tiny), int(h->tiny_ready), h->tiny_strikes, st[6], st[7], st[4], st[3], st[8], st[9], st[10], st[11], st[12]);
     if (!posdef && st[4] == 0 && h->learned < 3 && st[7] > 0) {
       // ---- learn: fold the pivot sequence the complete-pivoting kernel chose inside its blocks into the
       // elimination order, and remember where it took 2x2 pivots, so that later factorizations of
@@ -349,6 +381,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
         }
       for (int i = 0; i < n; ++i) order[seq[i]] = i + 1;
       if (moved) {
+        h->tiny_black.clear();
         int flag2;
         try {
           flag2 = symbolic_analyse(n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S);
@@ -387,6 +420,8 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     }
     total_moved += int(failed.size());
     h->learned = 0;       // the order changes: learn the in-block pivot sequence again afterwards
+    h->tiny_ready = false;
+    h->tiny_black.clear();
     int flag2;
     try {
       flag2 = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER,
@@ -403,6 +438,10 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     if (e != hipSuccess) return fail_hip(h, inform, e);
   }
 
+  if (!posdef) {
+    // the order is learned when (almost) every block went through the optimistic kernels
+    if (!tiny_off && !h->tiny_ready && h->tiny_strikes < 3) h->tiny_ready = (st[7] * 50 <= st[6] + st[7]);
+  }
   h->posdef = posdef != 0;
   inform->num_neg = 0;
   inform->num_two = 0;

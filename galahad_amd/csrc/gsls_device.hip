@@ -619,6 +619,106 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   STAMP(17);
 }
 
+// =================================================================================================
+// Whole-front LDL^T for TINY fronts (n <= 32 pivots, m <= 64 rows): one WAVE per front, four fronts per
+// workgroup, no LDS panel, no barriers, no MFMA.  Lane r holds row r of the front -- pivot rows and
+// contribution rows alike -- with the 32 columns in registers; the pivots run as in the serial stage of
+// k_diag_fast (given order, hinted 2x2 pivots, every pivot and multiplier tested), every row below takes
+// its update in the same instruction, and the contribution block C -= L21 D L21^T is formed from the same
+// registers.  A KKT tree is tens of thousands of such fronts: this replaces four launches of
+// workgroup-per-front kernels per level.  Any failed test only raises stat[13]; the host then repeats
+// the factorization on the workgroup path (which has the complete-pivoting fallback).
+// =================================================================================================
+struct TinyFrontTask {
+  int32_t n, m, ld, sptr;
+  int64_t loff, coff;
+  int32_t iblk, has_contrib, node, pad;
+};
+__global__ void __launch_bounds__(256)
+k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restrict__ L,
+             double* __restrict__ D, double* __restrict__ C, int32_t* __restrict__ stat,
+             int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
+             const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u) {
+  __shared__ double psh[4][2 * 32];   // per wave: the pivots d_k (for L*D)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ti = blockIdx.x * 4 + wave;
+  if (ti >= ntask) return;
+  const TinyFrontTask t = tasks[ti];
+  if (tinyskip[t.node]) return;      // a front this kernel could not take before: it is on the workgroup path
+  const int n = t.n, m = t.m, cm = m - n;
+  double* Lb = L + t.loff;
+  double* ps = psh[wave];
+  const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
+  double v[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) v[k] = (lane < m && k < n && lane >= k) ? Lb[int64_t(k) * t.ld + lane] : 0.0;
+  const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
+  const unsigned hmask = unsigned(__ballot(h2));
+  bool bad = false;
+  int nneg = 0;
+  double myd0 = 0.0, myd1 = 0.0;     // lane j: D entries of pivot j
+  // 1x1 pivots only: a front with a hinted 2x2 pivot is left to the workgroup kernels (a second code path
+  // per pivot would double an already fully unrolled body -- instruction fetch, not arithmetic, is the limit)
+  if (hmask != 0u) bad = true;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    // no break / continue in here: the loop must unroll completely (static register indices)
+    if (j < n) {
+      const double d = readlane_f64(v[j], j);
+      if (!(fabs(d) >= small)) bad = true;
+      if (d < 0.0) ++nneg;
+      double rd = __builtin_amdgcn_rcp(d);         // reciprocal + two Newton steps: full precision
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      const double own = v[j] * rd;
+      if (lane > j && lane < m && !(fabs(own) <= inv_u)) bad = true;   // threshold test, whole column
+      const double um = v[j];
+#pragma unroll
+      for (int k = j + 1; k < 32; ++k) {
+        const double lkj = readlane_f64(um, k);
+        v[k] = fma(-own, lkj, v[k]);
+      }
+      v[j] = (lane == j) ? 1.0 : own;
+      if (lane == j) { myd0 = rd; myd1 = 0.0; }
+      if (lane == 0) { ps[2 * j] = d; }
+    }
+  }
+  if (__ballot(bad) != 0ull) {
+    if (lane == 0) {
+      const int slot = atomicAdd(&stat[13], 1);
+      if (slot < FAILCAP) tinyfail[slot] = t.node;
+      fastok[t.iblk] = 0;
+    }
+    return;
+  }
+  // ---- factors out: column k of L (rows k..m-1), D, statistics ----------------------------------------
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    if (k < n && lane >= k && lane < m) Lb[int64_t(k) * t.ld + lane] = v[k];
+  if (lane < n) {
+    D[2 * int64_t(t.sptr + lane)] = myd0;
+    D[2 * int64_t(t.sptr + lane) + 1] = myd1;
+  }
+  if (lane == 0) {
+    fastok[t.iblk] = 1;
+    atomicAdd(&stat[6], 1);
+    if (nneg) atomicAdd(&stat[2], nneg);
+  }
+  if (!t.has_contrib || cm <= 0) return;
+  // ---- contribution block: C(i, j) -= sum_k (L D)(i, k) L(j, k) for the rows i >= j below the pivots -------
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  double ldv[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) ldv[k] = (k < n) ? v[k] * ps[2 * k] : 0.0;
+  double* Cb = C + t.coff;
+  for (int j = 0; j < cm; ++j) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = fma(ldv[k], readlane_f64(v[k], n + j), acc);
+    if (lane >= n + j && lane < m) Cb[int64_t(j) * cm + (lane - n)] -= acc;
+  }
+}
+
 // ---- LDL^T flavour: complete pivoting (1x1 and 2x2) inside the w x w diagonal block, applied to the
 // whole 128-row panel, a-posteriori threshold test |l_ij| <= 1/u on the rows below the block.
 // Behavioural model: block_ldlt<32> (ssids/cpu/kernels/block_ldlt.hxx:257-412: largest remaining
@@ -2109,10 +2209,10 @@ extern "C" void gsls_debug_stamps(unsigned long long* out) {
 #endif
 
 void dev_free(DeviceFactor& F) {
-  void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.asrc, F.adst, F.arow,
+  void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.tftasks, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.segC, F.segV, F.posowner};
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.posowner};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -2177,13 +2277,15 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<TileTask> tt;
   std::vector<PullSeg> psg;
   std::vector<TinyContribTask> tct;
+  std::vector<TinyFrontTask> tft;
   std::vector<PullTask> ptk;
   std::vector<int32_t> smalln, bign;
   std::vector<BigTrsv> btr;
   std::vector<BigGemv> bgm;
   int64_t part_max = 0;
   // one plan per node subset: everything (single device), my subtrees, the top part (multi-GPU)
-  auto build_plan = [&](std::vector<LevelPlan>& plan, auto keep) {
+  // wg(s): the front is factorized by the workgroup kernels (else: by k_front_tiny, a wave per front)
+  auto build_plan = [&](std::vector<LevelPlan>& plan, auto keep, auto wg) {
   plan.assign(S.nlevels, LevelPlan());
   std::vector<int> lvl_nodes;
   for (int l = 0; l < S.nlevels; ++l) {
@@ -2204,7 +2306,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       lp.panel_begin[2 * st_] = int(pt.size());
       for (int i = lp.node_begin; i < lp.node_end; ++i) {
         const int s = lvl_nodes[i];
-        if (S.ncol(s) > st_ * NB) {
+        if (S.ncol(s) > st_ * NB && wg(s)) {
           pt.push_back(PanelTask{s, st_, 0, 0});
           lp.panel_rows[st_] = std::max(lp.panel_rows[st_], std::min(PR, S.nrow(s) - st_ * NB));
         }
@@ -2213,7 +2315,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       lp.panel_begin[2 * st_ + 1] = int(pt.size());
       for (int i = lp.node_begin; i < lp.node_end; ++i) {
         const int s = lvl_nodes[i];
-        if (S.ncol(s) <= st_ * NB) continue;
+        if (S.ncol(s) <= st_ * NB || !wg(s)) continue;
         const int rem = S.nrow(s) - st_ * NB - PR;
         for (int c = 1; (c - 1) * RB < rem; ++c) pt.push_back(PanelTask{s, st_, c, 0});
       }
@@ -2223,6 +2325,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     lp.tinyc_begin = int(tct.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
       const int s = lvl_nodes[i];
+      if (!wg(s)) continue;              // k_front_tiny forms the contribution block itself
       if (S.sparent[s] >= nn) continue;  // roots have no (used) contribution block
       const int cm = S.nrow(s) - S.ncol(s);
       if (cm <= 16 && S.ncol(s) <= 64) {   // tiny: a wave per front (k_contrib_tiny)
@@ -2235,6 +2338,14 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     }
     lp.tile_cnt = int(tt.size()) - lp.tile_begin;
     lp.tinyc_cnt = int(tct.size()) - lp.tinyc_begin;
+    lp.tf_begin = int(tft.size());
+    for (int i = lp.node_begin; i < lp.node_end; ++i) {
+      const int s = lvl_nodes[i];
+      if (!wg(s))
+        tft.push_back(TinyFrontTask{S.ncol(s), S.nrow(s), S.ldl[s], S.sptr[s], S.loff[s], S.coff[s], nd[s].iblk,
+                                    (S.sparent[s] < nn) ? 1 : 0, s, 0});
+    }
+    lp.tf_cnt = int(tft.size()) - lp.tf_begin;
     // extend-add: one pull task per PCOLS columns of every parent, children in clist order
     lp.pull_begin = int(ptk.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
@@ -2305,11 +2416,14 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     }
   }
   };
-  build_plan(F.plan, [](int) { return true; });
+  auto all = [](int) { return true; };
+  build_plan(F.plan, all, all);
+  // the same schedule with the tiny fronts (n <= 32, m <= 64) handed to k_front_tiny (LDL^T refactorizations)
+  build_plan(F.planT, all, [&](int s) { return !(S.ncol(s) <= 32 && S.nrow(s) <= 64); });
   F.sharded = !S.owner.empty() && S.nranks > 1;
   if (F.sharded) {
-    build_plan(F.planA, [&](int s) { return S.owner[s] == F.myrank; });
-    build_plan(F.planB, [&](int s) { return S.owner[s] < 0; });
+    build_plan(F.planA, [&](int s) { return S.owner[s] == F.myrank; }, all);
+    build_plan(F.planB, [&](int s) { return S.owner[s] < 0; }, all);
   }
 
   HIPCHK(upload(F.nodes, nd, st));
@@ -2416,6 +2530,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     TinyContribTask* d3 = nullptr;
     HIPCHK(upload(d3, tct, st));
     F.tinyctasks = d3;
+    TinyFrontTask* d4 = nullptr;
+    HIPCHK(upload(d4, tft, st));
+    F.tftasks = d4;
   }
   HIPCHK(upload(F.asrc, asrc, st));
   HIPCHK(upload(F.adst, adst, st));
@@ -2437,6 +2554,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), 16 * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.faillist), FAILCAP * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.fastok), std::max<int64_t>(F.nblk64, 1) * sizeof(int32_t)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tinyskip), std::max(nn, 1)));
+  HIPCHK(hipMemsetAsync(F.tinyskip, 0, std::max(nn, 1), st));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tinyfail), FAILCAP * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.hint), std::max(S.n, 1)));
   HIPCHK(hipMemsetAsync(F.hint, 0, std::max(S.n, 1), st));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
@@ -2457,6 +2577,10 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
       hipLaunchKernelGGL(k_assemble_pull, dim3(lp.pull_cnt), dim3(256), 0, st,
                          static_cast<const PullTask*>(F.pulltasks) + lp.pull_begin,
                          static_cast<const PullSeg*>(F.pullsegs), F.cmap, F.L, F.C);
+    if (!POSDEF && lp.tf_cnt > 0)   // only in the tiny-front plan (planT)
+      hipLaunchKernelGGL(k_front_tiny, dim3((lp.tf_cnt + 3) / 4), dim3(256), 0, st,
+                         static_cast<const TinyFrontTask*>(F.tftasks) + lp.tf_begin, lp.tf_cnt, F.L, F.D, F.C,
+                         F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail, small, u);
     const int nsteps = int(lp.panel_cnt.size() / 2);
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
@@ -2491,6 +2615,23 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
                              F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u);
       }
     }
+    if (!POSDEF && &plan == &F.planT && l < int(F.bl_level.size()) && F.bl_level[l].np > 0) {
+      // tiny fronts that k_front_tiny could not take (blacklisted by the host): the workgroup kernels
+      const BlLevel& b = F.bl_level[l];
+      const int nrt = std::max(NB / 16, (b.rows + 15) / 16);
+      const int ldq = (16 * nrt) % 32 == 16 ? 16 * nrt : 16 * nrt + 16;
+      const size_t lds_fldl = sizeof(double) * ldq * (NB + 16);
+      hipLaunchKernelGGL((k_diag_fast<true, false>), dim3(b.np), dim3(256), lds_fldl, st, F.nodes,
+                         F.bl_ptasks + b.pbeg, F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u, ldq, nrt);
+      hipLaunchKernelGGL(k_diag_ldlt, dim3(b.np), dim3(256), lds_diag, st, F.nodes, F.bl_ptasks + b.pbeg, F.L, F.D,
+                         F.gperm, F.stat, F.faillist, F.fastok, small, u);
+      if (b.nt > 0)
+        hipLaunchKernelGGL(k_contrib<false>, dim3(b.nt), dim3(256), 0, st, F.nodes, F.bl_ttasks + b.tbeg, F.L, F.D,
+                           F.C);
+      if (b.ntc > 0)
+        hipLaunchKernelGGL(k_contrib_tiny<false>, dim3((b.ntc + 1) / 2), dim3(128), 0, st,
+                           static_cast<const TinyContribTask*>(F.bl_tctasks) + b.tcbeg, b.ntc, F.L, F.D, F.C);
+    }
     if (lp.tile_cnt > 0)
       hipLaunchKernelGGL(k_contrib<POSDEF>, dim3(lp.tile_cnt), dim3(256), 0, st, F.nodes,
                          F.ttasks + lp.tile_begin, F.L, F.D, F.C);
@@ -2502,6 +2643,55 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
   return hipGetLastError();
 }
 
+// Tiny fronts that k_front_tiny could not take go (back) to the workgroup kernels: per level a short
+// task list, rebuilt and uploaded whenever the blacklist grows (a few entries; no re-analysis).
+hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes,
+                                  hipStream_t st) {
+  const int nn = S.nnodes;
+  std::vector<uint8_t> skip(std::max(nn, 1), 0);
+  std::vector<std::vector<int>> per(S.nlevels);
+  for (int s : nodes) {
+    skip[s] = 1;
+    per[S.level[s]].push_back(s);
+  }
+  std::vector<PanelTask> pt;
+  std::vector<TileTask> tt;
+  std::vector<TinyContribTask> tc;
+  F.bl_level.assign(S.nlevels, BlLevel());
+  for (int l = 0; l < S.nlevels; ++l) {
+    BlLevel& b = F.bl_level[l];
+    b.pbeg = int(pt.size());
+    b.tbeg = int(tt.size());
+    b.tcbeg = int(tc.size());
+    for (int s : per[l]) {
+      pt.push_back(PanelTask{s, 0, 0, 0});
+      b.rows = std::max(b.rows, std::min(PR, S.nrow(s)));
+      if (S.sparent[s] >= nn) continue;
+      const int cm = S.nrow(s) - S.ncol(s);
+      if (cm <= 0) continue;
+      if (cm <= 16) tc.push_back(TinyContribTask{S.ncol(s), cm, S.ldl[s], S.sptr[s], S.loff[s], S.coff[s]});
+      else tt.push_back(TileTask{s, 0, 0, 0});
+    }
+    b.np = int(pt.size()) - b.pbeg;
+    b.nt = int(tt.size()) - b.tbeg;
+    b.ntc = int(tc.size()) - b.tcbeg;
+  }
+  for (void* p2 : {static_cast<void*>(F.bl_ptasks), static_cast<void*>(F.bl_ttasks), F.bl_tctasks})
+    if (p2) (void)hipFree(p2);
+  F.bl_ptasks = nullptr;
+  F.bl_ttasks = nullptr;
+  F.bl_tctasks = nullptr;
+  HIPCHK(upload(F.bl_ptasks, pt, st));
+  HIPCHK(upload(F.bl_ttasks, tt, st));
+  {
+    TinyContribTask* d = nullptr;
+    HIPCHK(upload(d, tc, st));
+    F.bl_tctasks = d;
+  }
+  HIPCHK(hipMemcpyAsync(F.tinyskip, skip.data(), skip.size(), hipMemcpyHostToDevice, st));
+  return hipStreamSynchronize(st);
+}
+
 // arena of the L11^-T blocks the Cholesky kernels exchange (one 64 x 64 block per 64 pivots)
 static hipError_t ensure_linv(DeviceFactor& F) {
   if (F.Linv) return hipSuccess;
@@ -2509,7 +2699,7 @@ static hipError_t ensure_linv(DeviceFactor& F) {
 }
 
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
-                      const double* d_scale, double small, double u, hipStream_t st) {
+                      const double* d_scale, double small, double u, hipStream_t st, bool use_tiny) {
   HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
   HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
   HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
@@ -2525,7 +2715,7 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
     HIPCHK(ensure_linv(F));
     return factor_levels<true>(S, F, F.plan, small, u, st);
   }
-  return factor_levels<false>(S, F, F.plan, small, u, st);
+  return factor_levels<false>(S, F, use_tiny ? F.planT : F.plan, small, u, st);
 }
 
 template <bool POSDEF>

@@ -46,11 +46,17 @@ struct LevelPlan {
   std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
   int tile_begin, tile_cnt;                 // range in the TileTask array
   int tinyc_begin, tinyc_cnt;               // fronts with a tiny contribution block (k_contrib_tiny)
+  int tf_begin = 0, tf_cnt = 0;             // whole tiny fronts (k_front_tiny), only in planT
   int pull_begin, pull_cnt;                 // extend-add tasks of the level (k_assemble_pull)
   int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
   int tiny_cnt;                             // ... of which the first tiny_cnt are tiny (n <= 64, m - n <= 64)
   int big_begin, big_cnt;                                // solve: blocked multi-launch fronts
   std::vector<BigStep> bigsteps;
+};
+
+// per level: tiny fronts blacklisted from k_front_tiny (ranges in bl_ptasks / bl_ttasks / bl_tctasks)
+struct BlLevel {
+  int pbeg = 0, np = 0, tbeg = 0, nt = 0, tcbeg = 0, ntc = 0, rows = 0;
 };
 
 struct DeviceFactor {
@@ -63,6 +69,13 @@ struct DeviceFactor {
   void* pullsegs = nullptr;        // extend-add: PullSeg / PullTask lists (gsls_device.hip)
   void* pulltasks = nullptr;
   void* tinyctasks = nullptr;
+  void* tftasks = nullptr;
+  uint8_t* tinyskip = nullptr;     // per node: 1 = not for k_front_tiny (blacklisted)
+  int32_t* tinyfail = nullptr;     // nodes k_front_tiny gave up on in the last pass (count in stat[13])
+  PanelTask* bl_ptasks = nullptr;
+  TileTask* bl_ttasks = nullptr;
+  void* bl_tctasks = nullptr;
+  std::vector<BlLevel> bl_level;
   int32_t* smallnodes = nullptr;
   void* stasks = nullptr;          // SolveTask per entry of smallnodes (same indexing)
   int32_t* gth_ptr = nullptr;      // forward solve: per row of every small front, range in gth_src
@@ -82,6 +95,7 @@ struct DeviceFactor {
   int32_t* gperm = nullptr;    // pivot slot -> analyse-time position (numerical pivoting)
   int64_t nscatter = 0;
   std::vector<LevelPlan> plan;    // every front (single device)
+  std::vector<LevelPlan> planT;   // LDL^T refactorizations: tiny fronts go to k_front_tiny, the rest as in `plan`
   std::vector<LevelPlan> planA;   // multi-GPU: the subtrees this rank owns
   std::vector<LevelPlan> planB;   // multi-GPU: the top part (run by rank 0 after the exchange)
   bool sharded = false;
@@ -118,7 +132,8 @@ struct DeviceFactor {
 hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st);
 void dev_free(DeviceFactor& F);
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
-                      const double* d_scale, double small, double u, hipStream_t st);
+                      const double* d_scale, double small, double u, hipStream_t st, bool use_tiny = false);
+hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);
 // multi-GPU phases (see gsls_shard_factor / gsls_shard_solve in include/gsls.h)
