@@ -1910,6 +1910,7 @@ k_solve_bwd_chol(const SolveTask* __restrict__ tasks, const int32_t* __restrict_
 // =================================================================================================
 constexpr int TINY_M = 128;
 
+template <int NMAX>   // NMAX = 32: fronts with at most 32 pivots (half the registers and instructions)
 __global__ void __launch_bounds__(256)
 k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* __restrict__ gth_ptr,
                  const int64_t* __restrict__ gth_src, const int32_t* __restrict__ gperm,
@@ -1923,11 +1924,11 @@ k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* 
   double* r = rsh[wave];
   const double* Lb = L + nd.loff;
   // row `lane` of the unit lower L11 and row n+lane of L21: coalesced along the lanes, all in flight
-  double row[64], low[64];
+  double row[NMAX], low[NMAX];
 #pragma unroll
-  for (int k = 0; k < 64; ++k) row[k] = (lane < n && k < lane) ? Lb[int64_t(k) * nd.ld + lane] : 0.0;
+  for (int k = 0; k < NMAX; ++k) row[k] = (lane < n && k < lane) ? Lb[int64_t(k) * nd.ld + lane] : 0.0;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) low[k] = (lane < cm && k < n) ? Lb[int64_t(k) * nd.ld + n + lane] : 0.0;
+  for (int k = 0; k < NMAX; ++k) low[k] = (lane < cm && k < n) ? Lb[int64_t(k) * nd.ld + n + lane] : 0.0;
   const int pslot = (lane < n) ? gperm[nd.sptr + lane] - nd.sptr : 0;   // pivot `lane` sits at this analyse position
   // right-hand side + the children's contribution vectors: every row of the front PULLS its sources in
   // child order (host-built gather lists: fixed summation order, and a front with hundreds of children
@@ -1941,17 +1942,18 @@ k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* 
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   double yv = (lane < n) ? r[pslot] : 0.0;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {      // unit lower triangular solve, one pivot per step
+  for (int k = 0; k < NMAX; ++k) {    // unit lower triangular solve, one pivot per step
     const double yk = readlane_f64(yv, k);
     yv = fma(-row[k], yk, yv);        // row[k] = 0 for k >= lane
   }
   if (lane < n) xp[nd.sptr + pslot] = yv;
   double acc = (lane < cm) ? r[n + lane] : 0.0;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) acc = fma(-low[k], readlane_f64(yv, k), acc);
+  for (int k = 0; k < NMAX; ++k) acc = fma(-low[k], readlane_f64(yv, k), acc);
   if (lane < cm) cvec[nd.moff + lane] = acc;
 }
 
+template <int NMAX>
 __global__ void __launch_bounds__(256)
 k_solve_bwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* __restrict__ rlist,
                  const int32_t* __restrict__ gperm, const double* __restrict__ L, double* __restrict__ xp) {
@@ -1963,9 +1965,9 @@ k_solve_bwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* 
   const int n = nd.n, m = nd.m, cm = m - n;
   double* z = zsh[wave];
   const double* col = L + nd.loff + int64_t(lane) * nd.ld;   // column `lane`: one contiguous stream per lane
-  double up[64];
+  double up[NMAX];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) up[j] = (lane < n && j > lane && j < n) ? col[j] : 0.0;   // L11(j, lane)
+  for (int j = 0; j < NMAX; ++j) up[j] = (lane < n && j > lane && j < n) ? col[j] : 0.0;   // L11(j, lane)
   const int pslot = (lane < n) ? gperm[nd.sptr + lane] : 0;
   double xv = (lane < n) ? xp[pslot] : 0.0;
   if (lane < cm) z[lane] = xp[rlist[nd.roff + n + lane]];
@@ -1981,7 +1983,7 @@ k_solve_bwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* 
     xv -= s0 + s1;
   }
 #pragma unroll
-  for (int j = 63; j >= 0; --j) {     // unit upper triangular solve, last pivot first
+  for (int j = NMAX - 1; j >= 0; --j) {   // unit upper triangular solve, last pivot first
     const double xj = readlane_f64(xv, j);
     xv = fma(-up[j], xj, xv);         // up[j] = 0 for j <= lane
   }
@@ -2373,20 +2375,22 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     lp.big_begin = int(bign.size());
     lp.small_maxn = lp.small_maxm = 0;
     int big_maxn = 0;
-    lp.tiny_cnt = 0;
-    for (int pass = 0; pass < 2; ++pass)      // tiny fronts first: the LDL^T solves give them a wave each
+    lp.tiny_cnt = lp.tiny32_cnt = 0;
+    for (int pass = 0; pass < 3; ++pass)      // tiny fronts first (<= 32 pivots, then <= 64): the LDL^T solves give them a wave each
       for (int i = lp.node_begin; i < lp.node_end; ++i) {
         const int s = lvl_nodes[i];
         const bool big = S.ncol(s) > BIG_N || S.nrow(s) > BIG_M;
         const bool tiny = S.ncol(s) <= 64 && S.nrow(s) - S.ncol(s) <= 64;
+        const int cls = !tiny ? 2 : (S.ncol(s) <= 32 ? 0 : 1);
         if (big) {
           if (pass == 0) {
             bign.push_back(s);
             big_maxn = std::max(big_maxn, S.ncol(s));
           }
-        } else if (tiny == (pass == 0)) {
+        } else if (cls == pass) {
           smalln.push_back(s);
           if (tiny) lp.tiny_cnt++;
+          if (cls == 0) lp.tiny32_cnt++;
           lp.small_maxn = std::max(lp.small_maxn, S.ncol(s));
           lp.small_maxm = std::max(lp.small_maxm, S.nrow(s));
         }
@@ -2740,9 +2744,13 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
                              xp, F.cvec);
         else {
           const SolveTask* stk = static_cast<const SolveTask*>(F.stasks) + lp.small_begin;
-          if (lp.tiny_cnt > 0)
-            hipLaunchKernelGGL(k_solve_fwd_tiny, dim3((lp.tiny_cnt + 3) / 4), dim3(256), 0, st, stk, lp.tiny_cnt,
-                               F.gth_ptr, F.gth_src, F.gperm, F.L, xp, F.cvec);
+          if (lp.tiny32_cnt > 0)
+            hipLaunchKernelGGL(k_solve_fwd_tiny<32>, dim3((lp.tiny32_cnt + 3) / 4), dim3(256), 0, st, stk,
+                               lp.tiny32_cnt, F.gth_ptr, F.gth_src, F.gperm, F.L, xp, F.cvec);
+          if (lp.tiny_cnt > lp.tiny32_cnt)
+            hipLaunchKernelGGL(k_solve_fwd_tiny<64>, dim3((lp.tiny_cnt - lp.tiny32_cnt + 3) / 4), dim3(256), 0, st,
+                               stk + lp.tiny32_cnt, lp.tiny_cnt - lp.tiny32_cnt, F.gth_ptr, F.gth_src, F.gperm, F.L, xp,
+                               F.cvec);
           if (lp.small_cnt > lp.tiny_cnt)
             hipLaunchKernelGGL(k_solve_fwd<false>, dim3(lp.small_cnt - lp.tiny_cnt), dim3(256),
                                sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
@@ -2800,9 +2808,12 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
             hipLaunchKernelGGL(k_solve_bwd<false>, dim3(lp.small_cnt - lp.tiny_cnt), dim3(256),
                                sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,
                                F.smallnodes + lp.small_begin + lp.tiny_cnt, F.rlist, F.gperm, F.L, xp);
-          if (lp.tiny_cnt > 0)
-            hipLaunchKernelGGL(k_solve_bwd_tiny, dim3((lp.tiny_cnt + 3) / 4), dim3(256), 0, st, stk, lp.tiny_cnt,
-                               F.rlist, F.gperm, F.L, xp);
+          if (lp.tiny_cnt > lp.tiny32_cnt)
+            hipLaunchKernelGGL(k_solve_bwd_tiny<64>, dim3((lp.tiny_cnt - lp.tiny32_cnt + 3) / 4), dim3(256), 0, st,
+                               stk + lp.tiny32_cnt, lp.tiny_cnt - lp.tiny32_cnt, F.rlist, F.gperm, F.L, xp);
+          if (lp.tiny32_cnt > 0)
+            hipLaunchKernelGGL(k_solve_bwd_tiny<32>, dim3((lp.tiny32_cnt + 3) / 4), dim3(256), 0, st, stk,
+                               lp.tiny32_cnt, F.rlist, F.gperm, F.L, xp);
         }
       }
     }

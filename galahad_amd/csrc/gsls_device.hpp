@@ -49,6 +49,7 @@ struct LevelPlan {
   int tf_begin = 0, tf_cnt = 0;             // whole tiny fronts (k_front_tiny), only in planT
   int pull_begin, pull_cnt;                 // extend-add tasks of the level (k_assemble_pull)
   int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
+  int tiny32_cnt = 0;                       // ... of which the first tiny32_cnt have n <= 32
   int tiny_cnt;                             // ... of which the first tiny_cnt are tiny (n <= 64, m - n <= 64)
   int big_begin, big_cnt;                                // solve: blocked multi-launch fronts
   std::vector<BigStep> bigsteps;
