@@ -1,6 +1,7 @@
 import csv,glob,sys,collections
 d=sys.argv[1]
-f=glob.glob(d+'/*/*_kernel_trace.csv')[0]
+import os
+f=max(glob.glob(d+'/*/*_kernel_trace.csv'), key=os.path.getmtime)
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 idx=[i for i,r in enumerate(rows) if 'k_iota' in r['Kernel_Name']]

@@ -6,7 +6,8 @@ import csv, glob, json, sys
 
 
 def load(d):
-    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    import os
+    f = max(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     return rows
