@@ -335,11 +335,13 @@ def test_full_size_cfg2_properties():
     s.terminate()
 
 
+@pytest.mark.parametrize("nemin", [64, 24, 8])
 @pytest.mark.parametrize("case", ["kkt", "grid_indef", "rand_indef", "kkt_perm_reversed"])
-def test_refactorization_after_learning(case):
+def test_refactorization_after_learning(case, nemin):
     """The handle learns from its first pivoted factorization (order repair, in-block pivot sequence,
-    2x2 positions) and later factorizations run the optimistic LDL^T kernel with the complete-pivoting
-    kernel as fallback.  Refactorizing the same values, and then values that drift as in an
+    2x2 positions) and later factorizations run the optimistic LDL^T kernels (workgroup per 64-column block;
+    with small node_amalgamation the wave-per-front kernel for tiny fronts and its blacklist) with the
+    complete-pivoting kernel as fallback.  Refactorizing the same values, and then values that drift as in an
     interior-point loop, must keep the inertia and the residual; against the oracle on the same matrix."""
     from galahad_amd import SLS, SMT, Control, InformSLS
     rng = np.random.default_rng(11)
@@ -358,12 +360,13 @@ def test_refactorization_after_learning(case):
     s, c, i = SLS(), Control(), InformSLS()
     s.initialize("gsls", c, i)
     c.pivot_control = 1
+    c.node_amalgamation = nemin
     s.analyse(m, c, i, PERM=perm)
     assert i.status == 0
     diag = np.where(row == col)[0]
     neg_ref = None
-    for it in range(4):
-        if it >= 2:   # drift the diagonal like barrier terms do (keeps the zero block of a KKT matrix zero)
+    for it in range(6):
+        if it >= 3:   # drift the diagonal like barrier terms do (keeps the zero block of a KKT matrix zero)
             nzd = diag[np.abs(m.val[diag]) > 0]
             m.val[nzd] *= 10.0 ** rng.uniform(-0.3, 0.3, len(nzd))
         s.factorize(m, c, i)
@@ -371,7 +374,7 @@ def test_refactorization_after_learning(case):
         b = P.sym_matvec(n, row - 1, col - 1, m.val, xs)
         x = s.solve(m, b, c, i)
         assert P.scaled_residual(n, row, col, m.val, x, b) <= 1e-10, it
-        if it < 2:
+        if it < 3:
             if neg_ref is None:
                 neg_ref = i.negative_eigenvalues
                 dense = np.zeros((n, n)) if n <= 700 else None
