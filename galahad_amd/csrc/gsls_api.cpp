@@ -423,6 +423,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     h->tiny_ready = false;
     h->tiny_black.clear();
     int flag2;
+    const double ta = now();
     try {
       flag2 = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER,
                                h->nemin, h->S);
@@ -432,10 +433,13 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     if (flag2 < 0) return inform->flag = flag2;
     fill_from_symbolic(h->S, inform);
     inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+    const double tb = now();
     e = dev_upload_symbolic(h->S, F, h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     e = stage_inputs();
     if (e != hipSuccess) return fail_hip(h, inform, e);
+    if (getenv("GSLS_DEBUG"))
+      fprintf(stderr, "[gsls] repair: re-analysis %.3f s, plan + upload %.3f s\n", tb - ta, now() - tb);
   }
 
   if (!posdef) {
