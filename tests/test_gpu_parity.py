@@ -384,3 +384,33 @@ def test_refactorization_after_learning(case, nemin):
                     assert neg_ref == int((np.linalg.eigvalsh(dense) < 0).sum())
             assert i.negative_eigenvalues == neg_ref      # same matrix: same inertia, whichever kernel ran
     s.terminate()
+
+
+@pytest.mark.parametrize("posdef", [True, False])
+def test_factor_with_scaling_vector(posdef):
+    """ssids_factor's optional `scale` (src/ssids/ssids.f90:770-779, fkeep.F90:229-318): the backend
+    factorizes S A S and the solve scales on the way in and out, so x solves the ORIGINAL system."""
+    import ctypes as C
+    from galahad_amd._lib import Inform, lib
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    prob = P.random_sparse(1500, 6, seed=21, spd=posdef)
+    n, row, col, val, rhs, xs = prob
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    c.pivot_control = 2 if posdef else 1
+    s.analyse(m, c, i)
+    assert i.status == 0
+    s._copy_control(c)
+    VAL = s.scatter_values(m)
+    scale = 10.0 ** np.random.default_rng(3).uniform(-2, 2, n)
+    ginf = Inform()
+    for rep in range(3):      # the refactorizations take the learned path
+        f = lib.gsls_factor(s.handle, 1 if posdef else 0, VAL.ctypes.data_as(C.c_void_p),
+                            scale.ctypes.data_as(C.c_void_p), C.byref(s.opts), C.byref(ginf))
+        assert f >= 0, (f, ginf.as_dict())
+        x = np.asfortranarray(rhs.copy())
+        f = lib.gsls_solve(s.handle, 0, 1, x.ctypes.data_as(C.c_void_p), n, C.byref(s.opts), C.byref(ginf))
+        assert f >= 0
+        assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-10
+    s.terminate()
