@@ -62,6 +62,12 @@ def parse():
     ap.add_argument("--shard", choices=["replicas", "tree"], default="replicas",
                     help="N>1: replicas = one independent system per GPU (weak scaling, the default); tree = "
                          "ONE system, elimination-tree subtrees dealt to the GPUs (strong scaling)")
+    ap.add_argument("--drift", type=int, default=0,
+                    help="kkt only: after the timed steps, run this many extra steps in which the diagonal of H changes "
+                         "like barrier terms of an interior-point loop (x 10^U(0,2) per entry and step: H stays positive "
+                         "definite, the inertia (n, m, 0) must not change) and report "
+                         "their time and how many blocks needed the pivoting fallback (extra field `drift`)")
+    ap.add_argument("--drift-decades", type=float, default=2.0, help="width of the drift: x 10^U(0, this)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     a = ap.parse_args()
@@ -219,6 +225,29 @@ def main():
     res = P.scaled_residual(n, row, col, val, x, rhs)
     assert res <= (1e-13 if posdef else 1e-10), res
 
+    drift = None
+    if kkt and a.drift > 0 and tsh is None:
+        # interior-point-like refactorizations: the diagonal of H (first entry of each of its CSC columns) drifts
+        didx = torch.from_numpy((s.PTR[: a.n] - 1).astype(np.int64)).cuda()
+        base = d_val[didx].clone()
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(7)
+        times, piv = [], []
+        fb, pb, bl = C.c_int32(), C.c_int32(), C.c_int32()
+        for _ in range(a.drift):
+            d_val[didx] = base * (10.0 ** (a.drift_decades * torch.rand(a.n, generator=gen, device="cuda", dtype=torch.float64)))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t1)
+            lib.gsls_get_factor_stats(s.handle, C.byref(fb), C.byref(pb), C.byref(bl))
+            piv.append(pb.value)
+        d_val[didx] = base
+        drift = {"steps": a.drift, "decades": a.drift_decades, "ms_per_step_median": float(np.median(times) * 1e3),
+                 "ms_per_step_max": float(np.max(times) * 1e3), "pivoted_blocks_max": int(max(piv)),
+                 "fast_blocks": fb.value, "tiny_blacklist": bl.value, "negative_eigenvalues": ginf.num_neg}
+
     if rank == 0:
         nnzL, flops_used = ginf.num_factor, ginf.num_flops      # of the order the timed steps used
         order = np.zeros(n, dtype=np.int32)
@@ -267,6 +296,8 @@ def main():
                          "frac": None if achieved is None else achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": solve_bytes, "seconds_per_launch": t_sweep},
         }
+        if drift is not None:
+            out["drift"] = drift
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(prob, posdef, order if (kkt or a.ordering == "natural") else np.arange(1, n + 1),
                               c.node_amalgamation)

@@ -30,6 +30,9 @@ struct Handle {
   bool tiny_ready = false;    // the order is learned: tiny fronts may go through the wave-per-front kernel
   int tiny_strikes = 0;       // factorizations in which that kernel met a pivot it could not take
   std::vector<int> tiny_black;   // tiny fronts that kernel gave up on: they stay on the workgroup path
+  int last_fast = 0, last_pivoted = 0, last_passes = 0;   // of the last factorization (gsls_get_factor_stats)
+  bool own_order = false;     // analyse chose the elimination order itself (it may be refined when values arrive)
+  bool preordered = false;    // ... and that refinement (zero-diagonal variables after their neighbours) has been done
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -223,6 +226,8 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
       h->ptr.assign(ptr, ptr + n + 1);
       h->row.assign(row, row + (ptr[n] - 1));
       h->nemin = options->nemin;
+      h->own_order = (options->ordering != GSLS_ORDER_USER);
+      h->preordered = false;
     }
   } catch (const std::bad_alloc&) {
     inform->stat = 1;
@@ -266,6 +271,57 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   hipError_t e = ensure_device(h, options);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   DeviceGuard g(h->device);
+  if (!posdef && h->own_order && !h->preordered) {
+    // Saddle-point structure: a variable whose diagonal entry is exactly zero (a constraint row of a KKT
+    // matrix) has no pivot of its own until its neighbours are eliminated, and how soon it gets a usable
+    // one depends on the VALUES of the others -- an order repaired for today's values fails tomorrow.
+    // Ordering every such variable after all of its neighbours makes its pivot the full Schur complement
+    // -(a H^-1 a^T): usable for any positive definite H.  Done once, when values are first seen.
+    h->preordered = true;
+    const int n = h->S.n;
+    const int64_t nzv = h->ptr[n] - 1;
+    std::vector<double> diag(n);
+    if (on_device) {
+      std::vector<double> hv(nzv);
+      e = hipMemcpy(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      for (int j = 0; j < n; ++j) diag[j] = hv[h->ptr[j] - 1];
+    } else {
+      for (int j = 0; j < n; ++j) diag[j] = val[h->ptr[j] - 1];
+    }
+    int nzero = 0;
+    for (int j = 0; j < n; ++j) nzero += (diag[j] == 0.0);
+    if (nzero > 0 && nzero < n) {
+      std::vector<int> nbmax(h->S.perm.begin(), h->S.perm.end());   // per variable: last position among its neighbours
+      for (int j = 0; j < n; ++j)
+        for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
+          const int i = h->row[k] - 1;
+          if (i == j) continue;
+          nbmax[i] = std::max(nbmax[i], h->S.perm[j]);
+          nbmax[j] = std::max(nbmax[j], h->S.perm[i]);
+        }
+      std::vector<double> key(n);
+      for (int v2 = 0; v2 < n; ++v2)
+        key[h->S.perm[v2]] = (diag[v2] == 0.0 && nbmax[v2] > h->S.perm[v2]) ? double(nbmax[v2]) + 0.5 : double(h->S.perm[v2]);
+      std::vector<int> idx(n);
+      for (int p2 = 0; p2 < n; ++p2) idx[p2] = p2;
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+      std::vector<int32_t> order(n);
+      for (int newpos = 0; newpos < n; ++newpos) order[h->S.invp[idx[newpos]]] = newpos + 1;
+      int flag2;
+      try {
+        flag2 = symbolic_analyse(n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S);
+      } catch (const std::bad_alloc&) {
+        return inform->flag = GSLS_ERROR_ALLOCATION;
+      }
+      if (flag2 < 0) return inform->flag = flag2;
+      fill_from_symbolic(h->S, inform);
+      inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+      h->last = *inform;
+      h->dev_ready = false;
+      if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] %d zero-diagonal variables ordered after their neighbours\n", nzero);
+    }
+  }
   if (!h->dev_ready) {
     e = dev_upload_symbolic(S, h->F, h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
@@ -446,6 +502,8 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     // the order is learned when (almost) every block went through the optimistic kernels
     if (!tiny_off && !h->tiny_ready && h->tiny_strikes < 3) h->tiny_ready = (st[7] * 50 <= st[6] + st[7]);
   }
+  h->last_fast = posdef ? 0 : st[6];
+  h->last_pivoted = posdef ? 0 : st[7];
   h->posdef = posdef != 0;
   inform->num_neg = 0;
   inform->num_two = 0;
@@ -845,6 +903,17 @@ int gsls_get_order(void* handle, int32_t* order) {
   Handle* h = static_cast<Handle*>(handle);
   if (!h || !h->analysed || !order) return GSLS_ERROR_CALL_SEQUENCE;
   for (int i = 0; i < h->S.n; ++i) order[i] = h->S.perm[i] + 1;
+  return GSLS_SUCCESS;
+}
+
+// how the last LDL^T factorization went: diagonal blocks / tiny fronts done optimistically, blocks that needed
+// the complete-pivoting kernel, tiny fronts currently kept off the wave-per-front kernel
+int gsls_get_factor_stats(void* handle, int32_t* fast_blocks, int32_t* pivoted_blocks, int32_t* tiny_blacklist) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
+  if (fast_blocks) *fast_blocks = h->last_fast;
+  if (pivoted_blocks) *pivoted_blocks = h->last_pivoted;
+  if (tiny_blacklist) *tiny_blacklist = int32_t(h->tiny_black.size());
   return GSLS_SUCCESS;
 }
 

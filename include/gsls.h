@@ -214,6 +214,10 @@ int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rp
  * given or computed, as repaired by factorizations that met delayed pivots; a valid PERM for SLS_analyse */
 int gsls_get_order(void* handle, int32_t* order);
 
+/* how the last LDL^T factorization went ("optimistic pass"): blocks / tiny fronts that passed the
+ * optimistic kernels, blocks redone by the complete-pivoting kernel, tiny fronts kept off the wave-per-front kernel */
+int gsls_get_factor_stats(void* handle, int32_t* fast_blocks, int32_t* pivoted_blocks, int32_t* tiny_blacklist);
+
 /* stream the handle launches on (hipStream_t as void*), and per-phase kernel timing of the last
  * solve measured with HIP events on that stream (seconds); used by bench.py's roofline block. */
 void* gsls_get_stream(void* handle);

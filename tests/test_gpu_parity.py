@@ -214,20 +214,43 @@ def test_refinement_reaches_1e14_on_indefinite():
 def test_delayed_pivots_are_repaired_and_remembered():
     """Failed pivots (the reference delays them to the parent front, assemble.hxx:244-264) become a
     repaired elimination order kept in the handle: inertia exact on the first factorization, and the
-    second factorization of the same structure needs no further repair."""
-    import time
-    prob = P.kkt_qpband(30000, 6000)
-    s, m, c, i = run_gsls(prob, False, ordering_free=True)
+    second factorization of the same structure needs no further repair.  The order is GIVEN here
+    (constraints first: every constraint meets a zero pivot), so the backend may not pre-order."""
+    prob = P.kkt_qpband(3000, 600)
+    n = prob[0]
+    s, m, c, i = run_gsls(prob, False, perm=np.arange(n, 0, -1))
     assert i.status == 0, i.gsls_inform
-    assert i.negative_eigenvalues == 6000 and i.rank == 36000
+    assert i.negative_eigenvalues == 600 and i.rank == 3600
     moved_first = i.delayed_pivots
-    assert moved_first > 0                        # the nested-dissection order does need delays here
+    assert moved_first > 0                        # this order does need delays
     x = s.solve(m, prob[4], c, i)
     assert P.scaled_residual(prob[0], prob[1], prob[2], prob[3], x, prob[4]) <= 1e-10
     s.factorize(m, c, i)
-    assert i.status == 0 and i.delayed_pivots == 0 and i.negative_eigenvalues == 6000
+    assert i.status == 0 and i.delayed_pivots == 0 and i.negative_eigenvalues == 600
     x2 = s.solve(m, prob[4], c, i)
     assert P.scaled_residual(prob[0], prob[1], prob[2], prob[3], x2, prob[4]) <= 1e-10
+    s.terminate()
+
+
+def test_saddle_point_order_is_value_independent():
+    """With its own ordering the backend puts every zero-diagonal variable (constraint row of a KKT
+    matrix) after all of its neighbours when the values first arrive: no delayed pivot on the first
+    factorization, none when the Hessian's diagonal drifts over four decades (interior-point barrier
+    terms), inertia (n, m, 0) throughout."""
+    prob = P.kkt_qpband(30000, 6000)
+    n, row, col, val, rhs, xs = prob
+    s, m, c, i = run_gsls(prob, False, ordering_free=True)
+    assert i.status == 0, i.gsls_inform
+    assert i.delayed_pivots == 0 and i.negative_eigenvalues == 6000 and i.rank == 36000
+    rng = np.random.default_rng(4)
+    hd = np.where((row == col) & (row <= 30000))[0]
+    for it in range(4):
+        m.val[hd] = val[hd] * 10.0 ** rng.uniform(-2, 2, len(hd)) + 2.0      # stays diagonally dominant: H > 0
+        s.factorize(m, c, i)
+        assert i.status == 0 and i.delayed_pivots == 0 and i.negative_eigenvalues == 6000, (it, i.gsls_inform)
+        b = P.sym_matvec(n, row - 1, col - 1, m.val, xs)
+        x = s.solve(m, b, c, i)
+        assert P.scaled_residual(n, row, col, m.val, x, b) <= 1e-10
     s.terminate()
 
 

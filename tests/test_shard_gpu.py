@@ -68,7 +68,9 @@ def test_tree_sharded_with_delayed_pivots(case, world, tmp_path):
     res = launch(case, world, tmp_path)
     for r in res:
         assert r["flag"] == 0, r
-        assert r["ref_delays"] > 0 and r["num_delay"] > 0, r
+        # (the single-device run pre-orders zero-diagonal variables and may need no delay at all; the sharded
+        # path keeps the analysed order and repairs it collectively)
+        assert r["num_delay"] > 0, r
         assert r["scaled_residual"] <= 1e-11, r
         assert r["max_abs_diff_vs_single"] <= 1e-8, r
         assert r["num_neg"] == r["ref_num_neg"], r
