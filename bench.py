@@ -178,7 +178,7 @@ def main():
     tsh = None
     if tree:
         from galahad_amd.shard import TreeShardedSLS
-        tsh = TreeShardedSLS(s)
+        tsh = TreeShardedSLS(s, d_val=None if posdef else d_val)
 
     def step():
         if tsh is not None:

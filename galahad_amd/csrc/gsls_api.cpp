@@ -243,6 +243,67 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
   return flag;
 }
 
+// Saddle-point structure: a variable whose diagonal entry is exactly zero (a constraint row of a KKT
+// matrix) has no pivot of its own until its neighbours are eliminated, and how soon it gets a usable
+// one depends on the VALUES of the others -- an order repaired for today's values fails tomorrow.
+// Ordering every such variable after all of its neighbours makes its pivot the full Schur complement
+// -(a H^-1 a^T): usable for any positive definite H.  Done once, when values are first seen, and only
+// if analyse chose the order itself.  Returns a gsls flag (0 also when there was nothing to do).
+static int refine_order_with_values(Handle* h, const double* val, bool on_device, gsls_inform* inform) {
+  if (!h->own_order || h->preordered) return GSLS_SUCCESS;
+  h->preordered = true;
+  const int n = h->S.n;
+  if (n == 0) return GSLS_SUCCESS;
+  const int64_t nzv = h->ptr[n] - 1;
+  std::vector<double> diag(n);
+  if (on_device) {
+    std::vector<double> hv(nzv);
+    hipError_t e = hipMemcpy(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    for (int j = 0; j < n; ++j) diag[j] = hv[h->ptr[j] - 1];
+  } else {
+    for (int j = 0; j < n; ++j) diag[j] = val[h->ptr[j] - 1];
+  }
+  int nzero = 0;
+  for (int j = 0; j < n; ++j) nzero += (diag[j] == 0.0);
+  if (nzero == 0 || nzero == n) return GSLS_SUCCESS;
+  std::vector<int> nbmax(h->S.perm.begin(), h->S.perm.end());   // per variable: last position among its neighbours
+  for (int j = 0; j < n; ++j)
+    for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
+      const int i = h->row[k] - 1;
+      if (i == j) continue;
+      nbmax[i] = std::max(nbmax[i], h->S.perm[j]);
+      nbmax[j] = std::max(nbmax[j], h->S.perm[i]);
+    }
+  std::vector<double> key(n);
+  for (int v2 = 0; v2 < n; ++v2)
+    key[h->S.perm[v2]] = (diag[v2] == 0.0 && nbmax[v2] > h->S.perm[v2]) ? double(nbmax[v2]) + 0.5 : double(h->S.perm[v2]);
+  std::vector<int> idx(n);
+  for (int p2 = 0; p2 < n; ++p2) idx[p2] = p2;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+  std::vector<int32_t> order(n);
+  for (int newpos = 0; newpos < n; ++newpos) order[h->S.invp[idx[newpos]]] = newpos + 1;
+  int flag2;
+  try {
+    flag2 = symbolic_analyse(n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S);
+  } catch (const std::bad_alloc&) {
+    return GSLS_ERROR_ALLOCATION;
+  }
+  if (flag2 < 0) return flag2;
+  if (inform) {
+    fill_from_symbolic(h->S, inform);
+    inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+    h->last = *inform;
+  } else {
+    fill_from_symbolic(h->S, &h->last);
+    h->last.factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+  }
+  h->dev_ready = false;
+  h->factored = false;
+  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] %d zero-diagonal variables ordered after their neighbours\n", nzero);
+  return GSLS_SUCCESS;
+}
+
 static int factor_common(Handle* h, int posdef, const double* val, const double* scale, bool on_device,
                          const gsls_options* options, gsls_inform* inform) {
   gsls_inform local;
@@ -271,56 +332,9 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   hipError_t e = ensure_device(h, options);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   DeviceGuard g(h->device);
-  if (!posdef && h->own_order && !h->preordered) {
-    // Saddle-point structure: a variable whose diagonal entry is exactly zero (a constraint row of a KKT
-    // matrix) has no pivot of its own until its neighbours are eliminated, and how soon it gets a usable
-    // one depends on the VALUES of the others -- an order repaired for today's values fails tomorrow.
-    // Ordering every such variable after all of its neighbours makes its pivot the full Schur complement
-    // -(a H^-1 a^T): usable for any positive definite H.  Done once, when values are first seen.
-    h->preordered = true;
-    const int n = h->S.n;
-    const int64_t nzv = h->ptr[n] - 1;
-    std::vector<double> diag(n);
-    if (on_device) {
-      std::vector<double> hv(nzv);
-      e = hipMemcpy(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) return fail_hip(h, inform, e);
-      for (int j = 0; j < n; ++j) diag[j] = hv[h->ptr[j] - 1];
-    } else {
-      for (int j = 0; j < n; ++j) diag[j] = val[h->ptr[j] - 1];
-    }
-    int nzero = 0;
-    for (int j = 0; j < n; ++j) nzero += (diag[j] == 0.0);
-    if (nzero > 0 && nzero < n) {
-      std::vector<int> nbmax(h->S.perm.begin(), h->S.perm.end());   // per variable: last position among its neighbours
-      for (int j = 0; j < n; ++j)
-        for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
-          const int i = h->row[k] - 1;
-          if (i == j) continue;
-          nbmax[i] = std::max(nbmax[i], h->S.perm[j]);
-          nbmax[j] = std::max(nbmax[j], h->S.perm[i]);
-        }
-      std::vector<double> key(n);
-      for (int v2 = 0; v2 < n; ++v2)
-        key[h->S.perm[v2]] = (diag[v2] == 0.0 && nbmax[v2] > h->S.perm[v2]) ? double(nbmax[v2]) + 0.5 : double(h->S.perm[v2]);
-      std::vector<int> idx(n);
-      for (int p2 = 0; p2 < n; ++p2) idx[p2] = p2;
-      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
-      std::vector<int32_t> order(n);
-      for (int newpos = 0; newpos < n; ++newpos) order[h->S.invp[idx[newpos]]] = newpos + 1;
-      int flag2;
-      try {
-        flag2 = symbolic_analyse(n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S);
-      } catch (const std::bad_alloc&) {
-        return inform->flag = GSLS_ERROR_ALLOCATION;
-      }
-      if (flag2 < 0) return inform->flag = flag2;
-      fill_from_symbolic(h->S, inform);
-      inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
-      h->last = *inform;
-      h->dev_ready = false;
-      if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] %d zero-diagonal variables ordered after their neighbours\n", nzero);
-    }
+  if (!posdef) {
+    const int rf = refine_order_with_values(h, val, on_device, inform);
+    if (rf < 0) return inform->flag = rf;
   }
   if (!h->dev_ready) {
     e = dev_upload_symbolic(S, h->F, h->stream);
@@ -904,6 +918,22 @@ int gsls_get_order(void* handle, int32_t* order) {
   if (!h || !h->analysed || !order) return GSLS_ERROR_CALL_SEQUENCE;
   for (int i = 0; i < h->S.n; ++i) order[i] = h->S.perm[i] + 1;
   return GSLS_SUCCESS;
+}
+
+// Give the handle the matrix values before the first factorization so that it can refine the elimination order it
+// chose itself (zero-diagonal variables after their neighbours, see refine_order_with_values).  gsls_factor does this
+// on its own; callers that split the tree over several GPUs call it on every rank BEFORE gsls_shard, because the
+// partition depends on the order.  d_val: device pointer, CSC order as for gsls_factor_dev.
+int gsls_refine_order_dev(void* handle, const double* d_val, gsls_inform* inform) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !d_val) return GSLS_ERROR_CALL_SEQUENCE;
+  gsls_inform local = h->last;
+  if (!inform) inform = &local;
+  else *inform = h->last;
+  DeviceGuard g(h->device);
+  const int rf = refine_order_with_values(h, d_val, true, inform);
+  inform->flag = rf;
+  return rf;
 }
 
 // how the last LDL^T factorization went: diagonal blocks / tiny fronts done optimistically, blocks that needed

@@ -24,7 +24,9 @@ from ._lib import Inform, lib
 class TreeShardedSLS:
     """Wraps an analysed galahad_amd.SLS object; all ranks must call every method collectively."""
 
-    def __init__(self, sls, group=None):
+    def __init__(self, sls, group=None, d_val=None):
+        """d_val (device tensor with the matrix values, optional): lets every rank refine its own ordering with
+        the values (gsls_refine_order_dev) before the tree is dealt -- same result on all ranks."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -34,6 +36,10 @@ class TreeShardedSLS:
         self.rank = dist.get_rank(group)
         if self.world < 2:
             raise ValueError("tree sharding needs at least two ranks; use SLS.factorize on one GPU")
+        if d_val is not None:
+            flag = lib.gsls_refine_order_dev(sls.handle, C.c_void_p(d_val.data_ptr()), None)
+            if flag < 0:
+                raise RuntimeError("gsls_refine_order_dev failed with flag %d" % flag)
         ce, ve = C.c_int64(), C.c_int64()
         flag = lib.gsls_shard(sls.handle, self.world, self.rank, C.byref(ce), C.byref(ve))
         if flag != 0:

@@ -214,6 +214,12 @@ int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rp
  * given or computed, as repaired by factorizations that met delayed pivots; a valid PERM for SLS_analyse */
 int gsls_get_order(void* handle, int32_t* order);
 
+/* Hand over the values before the first factorization so that an order chosen by analyse can be refined (zero-diagonal
+ * variables -- constraint rows of a saddle-point matrix -- after their neighbours: value-independent pivots).
+ * gsls_factor[_dev] does this itself on the first indefinite factorization; multi-GPU callers call it on every rank
+ * before gsls_shard (the partition depends on the order).  No reference counterpart: SSIDS delays pivots instead. */
+int gsls_refine_order_dev(void* handle, const double* d_val, gsls_inform* inform);
+
 /* how the last LDL^T factorization went ("optimistic pass"): blocks / tiny fronts that passed the
  * optimistic kernels, blocks redone by the complete-pivoting kernel, tiny fronts kept off the wave-per-front kernel */
 int gsls_get_factor_stats(void* handle, int32_t* fast_blocks, int32_t* pivoted_blocks, int32_t* tiny_blacklist);

@@ -25,8 +25,8 @@ def problem(case):
         return P.grid3d(12, 11, 10), False
     if case == "random_indef":             # mixed-sign diagonal, 2x2 pivots and a few delays
         return P.random_sparse(4000, 6, seed=11, spd=False), False
-    if case == "kkt_indef":                # saddle point: delayed pivots -> sharded order repair
-        return P.kkt_qpband(3000, 600, seed=3), False
+    if case in ("kkt_indef", "kkt_refined"):   # saddle point: delayed pivots -> sharded order repair, unless the
+        return P.kkt_qpband(3000, 600, seed=3), False      # order is refined with the values first (kkt_refined)
     if case == "grid2d_indef":
         return P.grid2d(60, 50, shift=1.0), False
     raise SystemExit("unknown case " + case)
@@ -62,9 +62,9 @@ def main():
     x1 = s1.solve(m, rhs.copy(), c1, i1)
 
     s2, c2, i2 = analysed()
-    ts = TreeShardedSLS(s2)
-    owner, cut = ts.partition()
     d_val = torch.from_numpy(s2.scatter_values(m)).cuda()
+    ts = TreeShardedSLS(s2, d_val=d_val if case == "kkt_refined" else None)
+    owner, cut = ts.partition()
     st = ts.factorize_dev(d_val, posdef)
     d_x = torch.from_numpy(rhs.copy()).cuda()
     ts.solve_dev(d_x)
