@@ -243,6 +243,22 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
   return flag;
 }
 
+// stat[] of the last factorization pass: copies the counters and folds the binned ones (device side: no
+// same-address atomics from tens of thousands of fronts) into st[2] (negative pivots) and st[6] (optimistic fronts)
+static hipError_t read_stat(Handle* h, int32_t (&st)[16]) {
+  int32_t all[NSTAT];
+  hipError_t e = hipMemcpyAsync(all, h->F.stat, sizeof(all), hipMemcpyDeviceToHost, h->stream);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return e;
+  for (int i = 0; i < 16; ++i) st[i] = all[i];
+  for (int b = 0; b < STAT_BINS; ++b) {
+    st[2] += all[16 + b];
+    st[6] += all[16 + STAT_BINS + b];
+  }
+  return hipSuccess;
+}
+
 // Saddle-point structure: a variable whose diagonal entry is exactly zero (a constraint row of a KKT
 // matrix) has no pivot of its own until its neighbours are eliminated, and how soon it gets a usable
 // one depends on the VALUES of the others -- an order repaired for today's values fails tomorrow.
@@ -385,9 +401,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     const bool use_tiny = !posdef && !scale && h->tiny_ready && !tiny_off;
     e = dev_factor(h->S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream, use_tiny);
     if (e != hipSuccess) return fail_hip(h, inform, e);
-    e = hipMemcpyAsync(st, F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
-    if (e != hipSuccess) return fail_hip(h, inform, e);
-    e = hipStreamSynchronize(h->stream);
+    e = read_stat(h, st);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     if (use_tiny && st[13] > 0) {
       // fronts the wave-per-front kernel gave up on join the blacklist (they take the workgroup kernels from
@@ -684,9 +698,7 @@ int gsls_shard_factor_dev(void* handle, int32_t phase, int32_t posdef, const dou
   e = dev_shard_factor(S, h->F, phase, posdef != 0, d_val, d_xchg, options->small, options->u, h->stream);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   int32_t st[16];
-  e = hipMemcpyAsync(st, h->F.stat, sizeof(st), hipMemcpyDeviceToHost, h->stream);
-  if (e != hipSuccess) return fail_hip(h, inform, e);
-  e = hipStreamSynchronize(h->stream);
+  e = read_stat(h, st);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   h->posdef = posdef != 0;
   inform->num_neg = inform->num_two = inform->num_delay = 0;

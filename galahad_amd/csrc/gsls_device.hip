@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "gsls_device.hpp"
 
@@ -701,8 +702,9 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
   }
   if (lane == 0) {
     fastok[t.iblk] = 1;
-    atomicAdd(&stat[6], 1);
-    if (nneg) atomicAdd(&stat[2], nneg);
+    // tens of thousands of fronts per launch: one shared counter would serialise them in L2
+    atomicAdd(&stat[16 + STAT_BINS + (ti & (STAT_BINS - 1))], 1);
+    if (nneg) atomicAdd(&stat[16 + (ti & (STAT_BINS - 1))], nneg);
   }
   if (!t.has_contrib || cm <= 0) return;
   // ---- contribution block: C(i, j) -= sum_k (L D)(i, k) L(j, k) for the rows i >= j below the pivots -------
@@ -2555,7 +2557,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.D), (2 * int64_t(S.n) + 4) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gperm), std::max(S.n, 1) * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), std::max<int64_t>(F.cvec_elems, 1) * sizeof(double)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), 16 * sizeof(int32_t)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), NSTAT * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.faillist), FAILCAP * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.fastok), std::max<int64_t>(F.nblk64, 1) * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tinyskip), std::max(nn, 1)));
@@ -2707,8 +2709,8 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
   HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
   HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
   HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
-  const int32_t init[16] = {INT_MAX, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(F.stat, init, sizeof(init), hipMemcpyHostToDevice, st));
+  static const std::vector<int32_t> init = [] { std::vector<int32_t> v(NSTAT, 0); v[0] = INT_MAX; return v; }();
+  HIPCHK(hipMemcpyAsync(F.stat, init.data(), NSTAT * sizeof(int32_t), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_iota, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm);
   if (F.nscatter > 0) {
     const int blocks = int(std::min<int64_t>((F.nscatter + 255) / 256, 256 * 8));
@@ -2866,8 +2868,8 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
     HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
     HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
     HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
-    const int32_t init[16] = {INT_MAX, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(F.stat, init, sizeof(init), hipMemcpyHostToDevice, st));
+    static const std::vector<int32_t> init = [] { std::vector<int32_t> v(NSTAT, 0); v[0] = INT_MAX; return v; }();
+    HIPCHK(hipMemcpyAsync(F.stat, init.data(), NSTAT * sizeof(int32_t), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_iota, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm);
     if (F.nscatter > 0) {
       const int blocks = int(std::min<int64_t>((F.nscatter + 255) / 256, 256 * 8));

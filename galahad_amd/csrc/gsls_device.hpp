@@ -14,6 +14,8 @@ constexpr int RB = 64;   // row-chunk height handled by one workgroup
 constexpr int TS = 64;   // contribution-block tile edge
 constexpr int BIG_N = 256;    // fronts wider / taller than this use the blocked multi-launch solve
 constexpr int BIG_M = 4096;
+constexpr int STAT_BINS = 64;            // per-front counters are spread over this many addresses (no same-address atomics)
+constexpr int NSTAT = 16 + 2 * STAT_BINS;  // stat[16..): negative-pivot bins, then optimistic-front bins
 constexpr int FAILCAP = 16384;  // capacity of the failed-pivot report of one factorization pass
 
 // One front.  L block: m x n column-major, leading dimension ld, at L + loff.
