@@ -713,11 +713,28 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
 #pragma unroll
   for (int k = 0; k < 32; ++k) ldv[k] = (k < n) ? v[k] * ps[2 * k] : 0.0;
   double* Cb = C + t.coff;
-  for (int j = 0; j < cm; ++j) {
-    double acc = 0.0;
+  for (int j0 = 0; j0 < cm; j0 += 8) {     // eight columns at a time: their loads of C are in flight together
+    double cold[8];                        // (one read-modify-write per column in turn cost a memory round trip each)
 #pragma unroll
-    for (int k = 0; k < 32; ++k) acc = fma(ldv[k], readlane_f64(v[k], n + j), acc);
-    if (lane >= n + j && lane < m) Cb[int64_t(j) * cm + (lane - n)] -= acc;
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q;
+      cold[q] = (j < cm && lane >= n + j && lane < m) ? Cb[int64_t(j) * cm + (lane - n)] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q;
+      if (j < cm) {                        // uniform
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = fma(ldv[k], readlane_f64(v[k], n + j), acc);
+        cold[q] -= acc;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q;
+      if (j < cm && lane >= n + j && lane < m) Cb[int64_t(j) * cm + (lane - n)] = cold[q];
+    }
   }
 }
 
