@@ -594,7 +594,9 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       if (__syncthreads_or((why >> b2) & 1) && tid == 0) atomicAdd(&stat[8 + b2], 1);
     if (tid == 0) {
       fastok[nd.iblk + t.step] = anybad ? 0 : 1;
-      atomicAdd(&stat[anybad ? 7 : 6], 1);         // statistics: blocks done optimistically / redone with pivoting
+      // statistics: blocks done optimistically (binned: no same-address atomics) / redone with pivoting (rare)
+      if (anybad) atomicAdd(&stat[7], 1);
+      else atomicAdd(&stat[16 + STAT_BINS + (blockIdx.x & (STAT_BINS - 1))], 1);
     }
     if (anybad) return;                              // k_diag_ldlt takes the block from the untouched input
     if (tid < w) {
@@ -602,7 +604,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       D[2 * int64_t(nd.sptr + kb + tid) + 1] = dgs(2 * tid + 1);
     }
     if (wave == fw && lane == 0) {
-      if (negacc) atomicAdd(&stat[2], negacc);
+      if (negacc) atomicAdd(&stat[16 + (blockIdx.x & (STAT_BINS - 1))], negacc);
       if (twoacc) atomicAdd(&stat[3], twoacc);
     }
   }
