@@ -117,17 +117,30 @@ bool repair_order(const Symbolic& S, const std::vector<int32_t>& failed_pos, std
   std::vector<double> key(n);
   for (int p = 0; p < n; ++p) key[p] = double(p);
   bool moved = false;
-  for (int32_t p : failed_pos) {
-    if (p < 0 || p >= n) continue;
-    const int s = int(std::upper_bound(S.sptr.begin(), S.sptr.begin() + nn + 1, p) - S.sptr.begin()) - 1;
-    if (s < 0 || s >= nn) continue;
-    const int blk = (p - S.sptr[s]) / NB, nblk = (S.ncol(s) + NB - 1) / NB;
-    int target;
-    if (blk < nblk - 1) target = S.sptr[s + 1] - 1;
-    else if (S.sparent[s] < nn) target = S.sptr[S.sparent[s] + 1] - 1;
-    else continue;
-    key[p] = double(target) + 0.5;
-    moved = true;
+  // failed_pos is sorted.  Consecutive failed positions of one front travel together (to the farthest of their
+  // targets): they are typically the two halves of a 2x2 pivot that a 64-column block boundary separated.
+  for (size_t a = 0; a < failed_pos.size();) {
+    size_t b = a;
+    int gtarget = -1, gnode = -1;
+    for (; b < failed_pos.size(); ++b) {
+      const int p = failed_pos[b];
+      if (p < 0 || p >= n) break;
+      if (b > a && p != failed_pos[b - 1] + 1) break;
+      const int s = int(std::upper_bound(S.sptr.begin(), S.sptr.begin() + nn + 1, p) - S.sptr.begin()) - 1;
+      if (s < 0 || s >= nn || (gnode >= 0 && s != gnode)) break;
+      gnode = s;
+      const int blk = (p - S.sptr[s]) / NB, nblk = (S.ncol(s) + NB - 1) / NB;
+      int target = -1;
+      if (blk < nblk - 1) target = S.sptr[s + 1] - 1;
+      else if (S.sparent[s] < nn) target = S.sptr[S.sparent[s] + 1] - 1;
+      gtarget = std::max(gtarget, target);
+    }
+    if (b == a) { ++a; continue; }       // out-of-range entry
+    if (gtarget >= 0) {
+      for (size_t q = a; q < b; ++q) key[failed_pos[q]] = double(gtarget) + 0.5;
+      moved = true;
+    }
+    a = b;
   }
   if (!moved) return false;
   std::vector<int> idx(n);
@@ -271,29 +284,64 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
   const int n = h->S.n;
   if (n == 0) return GSLS_SUCCESS;
   const int64_t nzv = h->ptr[n] - 1;
-  std::vector<double> diag(n);
+  std::vector<double> hv;
   if (on_device) {
-    std::vector<double> hv(nzv);
+    hv.resize(nzv);
     hipError_t e = hipMemcpy(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail_hip(h, inform, e);
-    for (int j = 0; j < n; ++j) diag[j] = hv[h->ptr[j] - 1];
-  } else {
-    for (int j = 0; j < n; ++j) diag[j] = val[h->ptr[j] - 1];
+    val = hv.data();
   }
+  std::vector<char> zero(n);
   int nzero = 0;
-  for (int j = 0; j < n; ++j) nzero += (diag[j] == 0.0);
-  if (nzero == 0 || nzero == n) return GSLS_SUCCESS;
-  std::vector<int> nbmax(h->S.perm.begin(), h->S.perm.end());   // per variable: last position among its neighbours
+  for (int j = 0; j < n; ++j) {
+    zero[j] = (val[h->ptr[j] - 1] == 0.0);
+    nzero += zero[j];
+  }
+  if (nzero == 0) return GSLS_SUCCESS;
+  const std::vector<int>& pos = h->S.perm;
+  // per variable: last position among its neighbours; for zero-diagonal variables also whether any neighbour
+  // has a diagonal entry, and the strongest coupling to another zero-diagonal variable
+  std::vector<int> nbmax(pos.begin(), pos.end()), best(n, -1);
+  std::vector<char> has_nz(n, 0);
+  std::vector<double> bestv(n, 0.0);
   for (int j = 0; j < n; ++j)
     for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
       const int i = h->row[k] - 1;
       if (i == j) continue;
-      nbmax[i] = std::max(nbmax[i], h->S.perm[j]);
-      nbmax[j] = std::max(nbmax[j], h->S.perm[i]);
+      nbmax[i] = std::max(nbmax[i], pos[j]);
+      nbmax[j] = std::max(nbmax[j], pos[i]);
+      const double av = std::fabs(val[k]);
+      if (zero[i]) {
+        if (!zero[j]) has_nz[i] = 1;
+        else if (av > bestv[i]) { bestv[i] = av; best[i] = j; }
+      }
+      if (zero[j]) {
+        if (!zero[i]) has_nz[j] = 1;
+        else if (av > bestv[j]) { bestv[j] = av; best[j] = i; }
+      }
     }
   std::vector<double> key(n);
-  for (int v2 = 0; v2 < n; ++v2)
-    key[h->S.perm[v2]] = (diag[v2] == 0.0 && nbmax[v2] > h->S.perm[v2]) ? double(nbmax[v2]) + 0.5 : double(h->S.perm[v2]);
+  for (int v2 = 0; v2 < n; ++v2) key[pos[v2]] = double(pos[v2]);
+  // (1) a zero-diagonal variable next to variables WITH a diagonal (constraint row of a KKT matrix): after all
+  //     of its neighbours -- its pivot becomes the full Schur complement, usable for any definite Hessian
+  // (2) one whose neighbours all have zero diagonals as well ([0 B; B^T 0]): it can only be eliminated in a
+  //     2x2 pivot; it is placed right behind its strongest partner so that the pair shares a diagonal block
+  std::vector<char> matched(n, 0);
+  int moved = 0;
+  for (int p2 = 0; p2 < n; ++p2) {
+    const int v2 = h->S.invp[p2];
+    if (!zero[v2] || matched[v2]) continue;
+    if (has_nz[v2]) {
+      if (nbmax[v2] > pos[v2]) { key[pos[v2]] = double(nbmax[v2]) + 0.5; ++moved; }
+    } else if (best[v2] >= 0 && !matched[best[v2]]) {
+      const int b2 = best[v2];
+      matched[v2] = matched[b2] = 1;
+      const int first = std::min(pos[v2], pos[b2]), second = std::max(pos[v2], pos[b2]);
+      key[second] = double(first) + 0.25;       // the later one of the pair moves up behind the earlier one
+      ++moved;
+    }
+  }
+  if (moved == 0) return GSLS_SUCCESS;
   std::vector<int> idx(n);
   for (int p2 = 0; p2 < n; ++p2) idx[p2] = p2;
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });

@@ -437,3 +437,35 @@ def test_factor_with_scaling_vector(posdef):
         assert f >= 0
         assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-10
     s.terminate()
+
+
+def test_all_zero_diagonal_saddle_needs_2x2_everywhere():
+    """K = [0 B; B^T 0]: no variable has a pivot of its own, every elimination is a 2x2 pivot.  The backend
+    pairs each variable with its strongest neighbour when the values arrive (so that partners share a
+    diagonal block) and keeps pairs together when a block boundary splits them; inertia (k, k, 0)."""
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    rng = np.random.default_rng(1)
+    nb = 700
+    n = 2 * nb
+    r, c, v = [], [], []
+    for i in range(nb):
+        for j in {i} | set(rng.integers(0, nb, 3).tolist()):
+            r.append(nb + j)
+            c.append(i)
+            v.append(2.0 + rng.uniform(0, 1) if j == i else rng.uniform(-0.3, 0.3))
+    row, col, val = np.array(r, dtype=np.int32) + 1, np.array(c, dtype=np.int32) + 1, np.array(v)
+    xs = rng.uniform(-1, 1, n)
+    rhs = P.sym_matvec(n, row - 1, col - 1, val, xs)
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s, ct, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", ct, i)
+    ct.pivot_control = 1
+    s.analyse(m, ct, i)
+    for rep in range(3):
+        s.factorize(m, ct, i)
+        assert i.status == 0, i.gsls_inform
+        assert i.negative_eigenvalues == nb and i.rank == n and i.two_by_two_pivots > 0
+        x = s.solve(m, rhs, ct, i)
+        assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-12
+    assert i.delayed_pivots == 0          # the repaired order is remembered
+    s.terminate()
