@@ -63,6 +63,7 @@ SIGNATURES = {
     "gsls_shard_get": (C.c_int, [C.c_void_p, p_i32, C.POINTER(i32), p_i32]),
     "gsls_get_order": (C.c_int, [C.c_void_p, p_i32]),
     "gsls_refine_order_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
+    "gsls_refine_order": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
     "gsls_get_factor_stats": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "gsls_get_stream": (C.c_void_p, [C.c_void_p]),
     "gsls_last_solve_kernel_seconds": (C.c_int, [C.c_void_p, p_f64, p_f64, p_f64]),

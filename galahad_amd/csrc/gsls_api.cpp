@@ -38,7 +38,15 @@ struct Handle {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   gsls_inform last;  // statistics of analyse (+factor), returned again by later phases
   std::vector<int64_t> ptr;   // the pattern given to analyse: needed again when failed pivots
-  std::vector<int32_t> row;   // force a repair of the elimination order (see repair_order)
+  std::vector<int32_t> row;   // force a repair of the elimination order (see plan_repair)
+  std::vector<int64_t> diagpos;   // per column: index of its diagonal entry in row/val, -1 if the pattern has none
+  std::vector<uint8_t> tppvar;    // per variable: 1 = the front that holds it is factorized by k_front_tpp
+  std::vector<uint8_t> tppfail;   // per variable: failures under whole-front pivoting (plan_repair)
+  std::vector<uint8_t> force;     // per variable: moved by a repair -- shares a supernode with its parent column
+  std::vector<int32_t> partner;   // per variable: the variable it was paired with by the pre-ordering, or -1
+  bool tpp_unflagged = false;     // the flags were dropped once after learning; if failures return they stay
+  bool tpp_dirty = false;
+  int shard_repairs = 0;          // repair rounds of the sharded path (plan_repair's pass counter)         // the device-side front flags no longer match tppvar / the current tree
   int nemin = 32;
   double kt_fwd = 0, kt_diag = 0, kt_bwd = 0;
 };
@@ -105,50 +113,110 @@ void fill_from_symbolic(const Symbolic& S, gsls_inform* inf) {
 // Delayed pivots, MI355X style.  The reference passes a pivot that fails the threshold test up to the
 // parent front at run time (ssids/cpu/kernels/assemble.hxx:244-264): front sizes change during the
 // factorization and its GPU path re-plans every level on the host.  Here the schedule is static, so a
-// failed pivot is turned into a change of the ELIMINATION ORDER instead: the variable is moved to the
-// end of its own supernode (if later 64-column blocks remain there) or to just after the last column
-// of the parent supernode, the symbolic analysis is redone for that order and the factorization
-// repeated.  The numerical effect is the same -- the variable is eliminated in the parent front,
-// after more of its row is fully summed -- and the repaired order is kept in the handle, so later
-// factorizations of the same structure (the interior-point loop of CQP/SBLS) start from it.
-// Returns false when nothing can be moved (failure in the last block of a root).
-bool repair_order(const Symbolic& S, const std::vector<int32_t>& failed_pos, std::vector<int32_t>& order) {
+// failed pivot becomes, in this order,
+//   1. a FLAG on its variable: the front that holds it is factorized by k_front_tpp from now on (threshold
+//      partial pivoting across ALL of the front's columns, the role of ldlt_tpp_factor on the columns the
+//      blocked kernel could not eliminate, factor.hxx:74-106) -- no change of the elimination order;
+//   2. if it fails there as well, a change of the ELIMINATION ORDER: the variable moves to just after the
+//      last column of the parent supernode (where more of its row is fully summed) and, should it fail
+//      once more, to the end of its tree's root; the symbolic analysis is redone and the factorization
+//      repeated.  Numerically this is the reference's delay; the flag travels with the variable, so the front
+//      it lands in searches all of its columns too.  A root front never reports failures (k_front_tpp
+//      records zero pivots there), so a variable fails at most three times.
+// Very wide fronts (> TPP_WIDE columns) first get the cheap repair -- the variable moves to the end of its
+// supernode, into the last 64-column block, where the blocked kernel's complete pivoting sees every remaining
+// column -- because one workgroup walking a 10^4-column front is slow; after a few passes they are flagged too.
+// The repaired order and the flags are kept in the handle, so later factorizations of the same structure
+// (the interior-point loop of CQP/SBLS) start from them.
+constexpr int TPP_WIDE = 1024;
+
+struct RepairPlan {
+  bool reorder = false;              // `order` holds a new elimination order: re-analyse
+  bool flagged = false;              // new variables were flagged: rebuild the front flags
+  std::vector<int32_t> order;
+};
+
+// tppfail[v]: how often variable v has failed under whole-front pivoting (first time: to the parent front;
+// again: to the root of its tree, where k_front_tpp cannot fail -- the delayed pivot that rides all the way up);
+// partner[v]: the variable v was matched with when the values arrived (zero-diagonal pairs, see
+// refine_order_with_values), -1 if none: a pair travels together, or the one left behind fails next.
+RepairPlan plan_repair(const Symbolic& S, const std::vector<int32_t>& failed_pos, std::vector<uint8_t>& tppvar,
+                       std::vector<uint8_t>& tppfail, std::vector<uint8_t>& force,
+                       const std::vector<int32_t>& partner, int pass) {
+  RepairPlan rp;
   const int n = S.n, nn = S.nnodes;
+  if (int(tppvar.size()) != n) tppvar.assign(n, 0);
+  if (int(tppfail.size()) != n) tppfail.assign(n, 0);
+  if (int(force.size()) != n) force.assign(n, 0);
   std::vector<double> key(n);
   for (int p = 0; p < n; ++p) key[p] = double(p);
-  bool moved = false;
-  // failed_pos is sorted.  Consecutive failed positions of one front travel together (to the farthest of their
-  // targets): they are typically the two halves of a 2x2 pivot that a 64-column block boundary separated.
-  for (size_t a = 0; a < failed_pos.size();) {
-    size_t b = a;
-    int gtarget = -1, gnode = -1;
-    for (; b < failed_pos.size(); ++b) {
-      const int p = failed_pos[b];
-      if (p < 0 || p >= n) break;
-      if (b > a && p != failed_pos[b - 1] + 1) break;
-      const int s = int(std::upper_bound(S.sptr.begin(), S.sptr.begin() + nn + 1, p) - S.sptr.begin()) - 1;
-      if (s < 0 || s >= nn || (gnode >= 0 && s != gnode)) break;
-      gnode = s;
+  std::vector<uint8_t> nodeflag(std::max(nn, 1), 0);
+  for (int s = 0; s < nn; ++s)
+    for (int p = S.sptr[s]; p < S.sptr[s + 1]; ++p)
+      if (tppvar[S.invp[p]]) { nodeflag[s] = 1; break; }
+  for (const int p : failed_pos) {
+    if (p < 0 || p >= n) continue;
+    const int s = int(std::upper_bound(S.sptr.begin(), S.sptr.begin() + nn + 1, p) - S.sptr.begin()) - 1;
+    if (s < 0 || s >= nn) continue;
+    const int v = S.invp[p];
+    if (!nodeflag[s]) {
+      // the blocked kernels failed here
       const int blk = (p - S.sptr[s]) / NB, nblk = (S.ncol(s) + NB - 1) / NB;
-      int target = -1;
-      if (blk < nblk - 1) target = S.sptr[s + 1] - 1;
-      else if (S.sparent[s] < nn) target = S.sptr[S.sparent[s] + 1] - 1;
-      gtarget = std::max(gtarget, target);
+      if (S.ncol(s) > TPP_WIDE && pass < 6) {
+        int target = -1;
+        if (blk < nblk - 1) target = S.sptr[s + 1] - 1;
+        else if (S.sparent[s] < nn) target = S.sptr[S.sparent[s] + 1] - 1;
+        if (target >= 0) {
+          key[p] = double(target) + 0.5;
+          rp.reorder = true;
+          continue;
+        }
+      }
+      tppvar[v] = 1;
+      rp.flagged = true;
+    } else {
+      // whole-front pivoting failed as well (k_front_tpp reports nothing at a root)
+      tppvar[v] = 1;
+      rp.flagged = true;
+      if (S.sparent[s] >= nn) continue;
+      int anc = S.sparent[s];
+      if (tppfail[v] < 255) ++tppfail[v];
+      if (tppfail[v] > 1)
+        while (S.sparent[anc] < nn) anc = S.sparent[anc];
+      const double k2 = double(S.sptr[anc + 1] - 1) + 0.5;
+      key[p] = std::max(key[p], k2);
+      force[v] = 1;
+      if (getenv("GSLS_DEBUG"))
+        fprintf(stderr, "[gsls]   var %d at pos %d (front %d: %d x %d, cols %d..%d, parent %d) failed %d times under whole-front pivoting -> behind pos %d (front %d), partner %d\n",
+                v, p, s, S.nrow(s), S.ncol(s), S.sptr[s], S.sptr[s + 1] - 1, S.sparent[s], int(tppfail[v]), S.sptr[anc + 1] - 1, anc,
+                (int(partner.size()) == n) ? partner[v] : -1);
+      const int w = (int(partner.size()) == n) ? partner[v] : -1;
+      if (w >= 0 && double(S.perm[w]) < k2) {
+        key[S.perm[w]] = std::max(key[S.perm[w]], k2);
+        tppvar[w] = 1;
+        force[w] = 1;
+      }
+      rp.reorder = true;
     }
-    if (b == a) { ++a; continue; }       // out-of-range entry
-    if (gtarget >= 0) {
-      for (size_t q = a; q < b; ++q) key[failed_pos[q]] = double(gtarget) + 0.5;
-      moved = true;
-    }
-    a = b;
   }
-  if (!moved) return false;
-  std::vector<int> idx(n);
-  for (int p = 0; p < n; ++p) idx[p] = p;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
-  order.assign(n, 0);
-  for (int newpos = 0; newpos < n; ++newpos) order[S.invp[idx[newpos]]] = newpos + 1;
-  return true;
+  if (rp.reorder) {
+    std::vector<int> idx(n);
+    for (int p = 0; p < n; ++p) idx[p] = p;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+    rp.order.assign(n, 0);
+    for (int newpos = 0; newpos < n; ++newpos) rp.order[S.invp[idx[newpos]]] = newpos + 1;
+  }
+  return rp;
+}
+
+// the fronts that hold a flagged variable, for dev_set_tpp
+std::vector<int> tpp_nodes(const Symbolic& S, const std::vector<uint8_t>& tppvar) {
+  std::vector<int> nodes;
+  if (int(tppvar.size()) != S.n) return nodes;
+  for (int s = 0; s < S.nnodes; ++s)
+    for (int p = S.sptr[s]; p < S.sptr[s + 1]; ++p)
+      if (tppvar[S.invp[p]]) { nodes.push_back(s); break; }
+  return nodes;
 }
 
 }  // namespace
@@ -238,6 +306,16 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
       flag = symbolic_analyse(n, ptr, row, order, options->ordering, options->nemin, h->S);
       h->ptr.assign(ptr, ptr + n + 1);
       h->row.assign(row, row + (ptr[n] - 1));
+      h->diagpos.assign(n, -1);
+      for (int j = 0; j < n; ++j)
+        for (int64_t k = ptr[j] - 1; k < ptr[j + 1] - 1; ++k)
+          if (row[k] == j + 1) { h->diagpos[j] = k; break; }
+      h->tppvar.assign(n, 0);
+      h->tppfail.assign(n, 0);
+      h->force.assign(n, 0);
+      h->partner.assign(n, -1);
+      h->tpp_unflagged = false;
+      h->tpp_dirty = true;
       h->nemin = options->nemin;
       h->own_order = (options->ordering != GSLS_ORDER_USER);
       h->preordered = false;
@@ -278,6 +356,8 @@ static hipError_t read_stat(Handle* h, int32_t (&st)[16]) {
 // Ordering every such variable after all of its neighbours makes its pivot the full Schur complement
 // -(a H^-1 a^T): usable for any positive definite H.  Done once, when values are first seen, and only
 // if analyse chose the order itself.  Returns a gsls flag (0 also when there was nothing to do).
+static int reanalyse(Handle* h, std::vector<int32_t>& order, gsls_inform* inform);
+
 static int refine_order_with_values(Handle* h, const double* val, bool on_device, gsls_inform* inform) {
   if (!h->own_order || h->preordered) return GSLS_SUCCESS;
   h->preordered = true;
@@ -291,10 +371,22 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
     if (e != hipSuccess) return fail_hip(h, inform, e);
     val = hv.data();
   }
+  // "zero diagonal": no diagonal entry in the pattern, or one that is negligible beside the column's other
+  // entries (a 1e-8 regularisation block would fail every threshold test as a pivot of its own, just like 0)
+  std::vector<double> cmax(n, 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
+      const int i = h->row[k] - 1;
+      if (i == j) continue;
+      const double av = std::fabs(val[k]);
+      cmax[i] = std::max(cmax[i], av);
+      cmax[j] = std::max(cmax[j], av);
+    }
   std::vector<char> zero(n);
   int nzero = 0;
   for (int j = 0; j < n; ++j) {
-    zero[j] = (val[h->ptr[j] - 1] == 0.0);
+    const double dj = (h->diagpos[j] >= 0) ? std::fabs(val[h->diagpos[j]]) : 0.0;
+    zero[j] = (dj == 0.0) || (dj <= 1e-8 * cmax[j]);
     nzero += zero[j];
   }
   if (nzero == 0) return GSLS_SUCCESS;
@@ -336,8 +428,11 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
     } else if (best[v2] >= 0 && !matched[best[v2]]) {
       const int b2 = best[v2];
       matched[v2] = matched[b2] = 1;
+      h->partner[v2] = b2;
+      h->partner[b2] = v2;
       const int first = std::min(pos[v2], pos[b2]), second = std::max(pos[v2], pos[b2]);
       key[second] = double(first) + 0.25;       // the later one of the pair moves up behind the earlier one
+      h->force[h->S.invp[first]] = 1;           // ... and the two share a supernode (its parent column is the partner)
       ++moved;
     }
   }
@@ -347,24 +442,39 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
   std::vector<int32_t> order(n);
   for (int newpos = 0; newpos < n; ++newpos) order[h->S.invp[idx[newpos]]] = newpos + 1;
-  int flag2;
-  try {
-    flag2 = symbolic_analyse(n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S);
-  } catch (const std::bad_alloc&) {
-    return GSLS_ERROR_ALLOCATION;
-  }
-  if (flag2 < 0) return flag2;
-  if (inform) {
-    fill_from_symbolic(h->S, inform);
-    inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
-    h->last = *inform;
-  } else {
-    fill_from_symbolic(h->S, &h->last);
-    h->last.factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
-  }
+  const int rf = reanalyse(h, order, inform);
+  if (rf < 0) return rf;
+  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] %d zero-diagonal variables ordered after their neighbours\n", nzero);
+  return GSLS_SUCCESS;
+}
+
+// Re-analyse in place for a new elimination order (order repair, learned pivot sequence, pre-ordering).  The
+// handle is consistent whatever happens: device plans are dropped first, and a failed analysis leaves the
+// handle un-analysed instead of half-built.
+static int reanalyse(Handle* h, std::vector<int32_t>& order, gsls_inform* inform) {
   h->dev_ready = false;
   h->factored = false;
-  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] %d zero-diagonal variables ordered after their neighbours\n", nzero);
+  int flag2;
+  try {
+    flag2 = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S,
+                             (int(h->force.size()) == h->S.n) ? h->force.data() : nullptr);
+  } catch (const std::bad_alloc&) {
+    h->analysed = false;
+    return GSLS_ERROR_ALLOCATION;
+  }
+  if (flag2 < 0) {
+    h->analysed = false;
+    return flag2;
+  }
+  gsls_inform* dst = inform ? inform : &h->last;
+  fill_from_symbolic(h->S, dst);
+  dst->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+  if (inform) {
+    const int keep = h->last.flag;
+    h->last = *inform;
+    h->last.flag = keep;
+  }
+  h->tpp_dirty = true;
   return GSLS_SUCCESS;
 }
 
@@ -400,11 +510,6 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     const int rf = refine_order_with_values(h, val, on_device, inform);
     if (rf < 0) return inform->flag = rf;
   }
-  if (!h->dev_ready) {
-    e = dev_upload_symbolic(S, h->F, h->stream);
-    if (e != hipSuccess) return fail_hip(h, inform, e);
-    h->dev_ready = true;
-  }
   DeviceFactor& F = h->F;
   const double* d_val = val;
   const double* d_scale = scale;
@@ -435,18 +540,41 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     }
     return hipSuccess;
   };
-  e = stage_inputs();
-  if (e != hipSuccess) return fail_hip(h, inform, e);
+  // (re)build everything on the device that depends on the current tree: plans, staged inputs, front flags
+  auto sync_device = [&]() -> hipError_t {
+    if (!h->dev_ready) {
+      hipError_t e2 = dev_upload_symbolic(h->S, F, h->stream);
+      if (e2 != hipSuccess) return e2;
+      h->dev_ready = true;
+      h->tpp_dirty = true;
+      e2 = stage_inputs();
+      if (e2 != hipSuccess) return e2;
+    }
+    if (h->tpp_dirty) {
+      hipError_t e2 = dev_set_tpp(h->S, F, posdef ? std::vector<int>() : tpp_nodes(h->S, h->tppvar), h->stream);
+      if (e2 != hipSuccess) return e2;
+      h->tpp_dirty = false;
+    }
+    return hipSuccess;
+  };
+  {
+    const bool fresh = !h->dev_ready;
+    e = sync_device();
+    if (e == hipSuccess && !fresh) e = stage_inputs();
+    if (e != hipSuccess) { h->dev_ready = false; return fail_hip(h, inform, e); }
+  }
   h->have_scale = (scale != nullptr);
   int32_t st[16];
   int total_moved = 0;
   bool tiny_off = false;
   int tiny_repeats = 0;
-  const int max_pass = 200;
+  const int max_pass = 60;    // a variable fails at most three times (plan_repair); cascades end long before this
   for (int pass = 0;; ++pass) {
     // refactorizations of a learned order: tiny fronts whole, a wave each (k_front_tiny); if that kernel
     // meets a pivot it cannot take (stat[13]) the pass is repeated on the workgroup path
-    const bool use_tiny = !posdef && !scale && h->tiny_ready && !tiny_off;
+    bool any_tpp = false;
+    for (const auto& c : F.tpp_cnt[0]) any_tpp |= (c > 0);
+    const bool use_tiny = !posdef && !scale && h->tiny_ready && !tiny_off && !any_tpp;
     e = dev_factor(h->S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream, use_tiny);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     e = read_stat(h, st);
@@ -473,10 +601,10 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       continue;
     }
     if (getenv("GSLS_DEBUG"))
-      fprintf(stderr, "[gsls] pass %d (tiny %d ready %d strikes %d): blocks fast %d, pivoted %d, failed columns %d, 2x2 %d | why: small %d inblock %d straddle %d rej2x2 %d below %d\n", pass, int(use_tiny), int(h->tiny_ready), h->tiny_strikes, st[6], st[7], st[4], st[3], st[8], st[9], st[10], st[11], st[12]);
-    if (!posdef && st[4] == 0 && h->learned < 3 && st[7] > 0) {
-      // ---- learn: fold the pivot sequence the complete-pivoting kernel chose inside its blocks into the
-      // elimination order, and remember where it took 2x2 pivots, so that later factorizations of
+      fprintf(stderr, "[gsls] pass %d (tiny %d ready %d strikes %d): blocks fast %d, pivoted %d, tpp fronts %d (left %d), failed columns %d, 2x2 %d | why: small %d inblock %d straddle %d rej2x2 %d below %d\n", pass, int(use_tiny), int(h->tiny_ready), h->tiny_strikes, st[6], st[7], st[14], st[15], st[4], st[3], st[8], st[9], st[10], st[11], st[12]);
+    if (!posdef && st[4] == 0 && h->learned < 3 && (st[7] > 0 || st[14] > 0)) {
+      // ---- learn: fold the pivot sequence the pivoting kernels chose inside their blocks / fronts into the
+      // elimination order, and remember where they took 2x2 pivots, so that later factorizations of
       // this pattern (the next interior-point iterations) go through the optimistic kernel
       h->learned += 1;
       const int n = h->S.n;
@@ -512,21 +640,23 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
           moved = true;
         }
       for (int i = 0; i < n; ++i) order[seq[i]] = i + 1;
+      // the learned sequence is tried on the blocked kernels again: whole-front pivoting only where it is
+      // needed once more
+      const bool had_flags = !h->tpp_unflagged && !h->tppvar.empty() &&
+                             std::any_of(h->tppvar.begin(), h->tppvar.end(), [](uint8_t f) { return f != 0; });
+      if (had_flags) {
+        h->tpp_unflagged = true;
+        std::fill(h->tppvar.begin(), h->tppvar.end(), uint8_t(0));
+        h->tpp_dirty = true;
+      }
       if (moved) {
         h->tiny_black.clear();
-        int flag2;
-        try {
-          flag2 = symbolic_analyse(n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin, h->S);
-        } catch (const std::bad_alloc&) {
-          return inform->flag = GSLS_ERROR_ALLOCATION;
-        }
-        if (flag2 < 0) return inform->flag = flag2;
-        fill_from_symbolic(h->S, inform);
-        inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
-        e = dev_upload_symbolic(h->S, F, h->stream);
-        if (e != hipSuccess) return fail_hip(h, inform, e);
-        e = stage_inputs();
-        if (e != hipSuccess) return fail_hip(h, inform, e);
+        const int rf = reanalyse(h, order, inform);
+        if (rf < 0) return inform->flag = rf;
+      }
+      if (moved || had_flags) {
+        e = sync_device();
+        if (e != hipSuccess) { h->dev_ready = false; return fail_hip(h, inform, e); }
       }
       if (moved || any2) {
         e = hipMemcpy(F.hint, hints.data(), size_t(n), hipMemcpyHostToDevice);
@@ -535,57 +665,51 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       if (moved) continue;     // factorize once more in the learned order
     }
     if (posdef || st[4] == 0) break;
-    // ---- some pivots failed: repair the elimination order and go again ---------------------------
+    // ---- some pivots failed: flag their fronts for whole-front pivoting, or (second failure) move them up ----
     const int nf = std::min<int>(st[5], FAILCAP);
-    std::vector<int32_t> failed(nf), order;
+    std::vector<int32_t> failed(nf);
     if (nf > 0) {
       e = hipMemcpy(failed.data(), F.faillist, nf * sizeof(int32_t), hipMemcpyDeviceToHost);
       if (e != hipSuccess) return fail_hip(h, inform, e);
     }
     std::sort(failed.begin(), failed.end());
     failed.erase(std::unique(failed.begin(), failed.end()), failed.end());
-    if (pass >= max_pass || !repair_order(h->S, failed, order)) {
+    RepairPlan rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, pass);
+    if (pass >= max_pass || (!rp.reorder && !rp.flagged)) {
       inform->num_delay = total_moved;
-      inform->flag = GSLS_ERROR_UNIMPLEMENTED;   // could not place the failed pivots
+      inform->flag = GSLS_ERROR_UNIMPLEMENTED;   // not reached in any test: every failing variable ends at a root
       inform->time_factor = now() - t0;
       return inform->flag;
     }
     total_moved += int(failed.size());
-    h->learned = 0;       // the order changes: learn the in-block pivot sequence again afterwards
     h->tiny_ready = false;
     h->tiny_black.clear();
-    int flag2;
+    h->tpp_dirty = true;
     const double ta = now();
-    try {
-      flag2 = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER,
-                               h->nemin, h->S);
-    } catch (const std::bad_alloc&) {
-      return inform->flag = GSLS_ERROR_ALLOCATION;
+    if (rp.reorder) {
+      h->learned = 0;       // the order changes: learn the in-block pivot sequence again afterwards
+      const int rf = reanalyse(h, rp.order, inform);
+      if (rf < 0) return inform->flag = rf;
     }
-    if (flag2 < 0) return inform->flag = flag2;
-    fill_from_symbolic(h->S, inform);
-    inform->factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
     const double tb = now();
-    e = dev_upload_symbolic(h->S, F, h->stream);
-    if (e != hipSuccess) return fail_hip(h, inform, e);
-    e = stage_inputs();
-    if (e != hipSuccess) return fail_hip(h, inform, e);
+    e = sync_device();
+    if (e != hipSuccess) { h->dev_ready = false; return fail_hip(h, inform, e); }
     if (getenv("GSLS_DEBUG"))
-      fprintf(stderr, "[gsls] repair: re-analysis %.3f s, plan + upload %.3f s\n", tb - ta, now() - tb);
+      fprintf(stderr, "[gsls] repair (%s): re-analysis %.3f s, plan + upload %.3f s\n", rp.reorder ? "order" : "flags", tb - ta, now() - tb);
   }
 
   if (!posdef) {
     // the order is learned when (almost) every block went through the optimistic kernels
-    if (!tiny_off && !h->tiny_ready && h->tiny_strikes < 3) h->tiny_ready = (st[7] * 50 <= st[6] + st[7]);
+    if (!tiny_off && !h->tiny_ready && h->tiny_strikes < 3 && st[14] == 0) h->tiny_ready = (st[7] * 50 <= st[6] + st[7]);
   }
   h->last_fast = posdef ? 0 : st[6];
-  h->last_pivoted = posdef ? 0 : st[7];
+  h->last_pivoted = posdef ? 0 : st[7] + st[14];
   h->posdef = posdef != 0;
   inform->num_neg = 0;
   inform->num_two = 0;
   inform->num_delay = 0;
-  inform->matrix_rank = S.sptr[S.nnodes];
-  inform->maxfront = std::max(S.maxfront, S.maxrow);   // cpu_iface.f90:84
+  inform->matrix_rank = h->S.sptr[h->S.nnodes];
+  inform->maxfront = std::max(h->S.maxfront, h->S.maxrow);   // cpu_iface.f90:84
   if (posdef) {
     if (st[0] != INT_MAX) {
       inform->flag = GSLS_ERROR_NOT_POS_DEF;
@@ -741,6 +865,12 @@ int gsls_shard_factor_dev(void* handle, int32_t phase, int32_t posdef, const dou
     e = dev_upload_symbolic(S, h->F, h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     h->dev_ready = true;
+    h->tpp_dirty = true;
+  }
+  if (h->tpp_dirty) {
+    e = dev_set_tpp(S, h->F, posdef ? std::vector<int>() : tpp_nodes(S, h->tppvar), h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    h->tpp_dirty = false;
   }
   h->have_scale = false;
   e = dev_shard_factor(S, h->F, phase, posdef != 0, d_val, d_xchg, options->small, options->u, h->stream);
@@ -826,21 +956,17 @@ int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed_in, i
   Handle* h = static_cast<Handle*>(handle);
   if (!h || !h->analysed || h->S.nranks < 2 || nfailed < 0 || (nfailed > 0 && !failed_in))
     return GSLS_ERROR_CALL_SEQUENCE;
-  std::vector<int32_t> failed(failed_in, failed_in + nfailed), order;
+  std::vector<int32_t> failed(failed_in, failed_in + nfailed);
   std::sort(failed.begin(), failed.end());
   failed.erase(std::unique(failed.begin(), failed.end()), failed.end());
-  if (!repair_order(h->S, failed, order)) return GSLS_ERROR_UNIMPLEMENTED;
+  RepairPlan rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, h->shard_repairs++);
+  if (!rp.reorder && !rp.flagged) return GSLS_ERROR_UNIMPLEMENTED;
   const int nranks = h->S.nranks, rank = h->F.myrank;
-  int flag;
-  try {
-    flag = symbolic_analyse(h->S.n, h->ptr.data(), h->row.data(), order.data(), GSLS_ORDER_USER, h->nemin,
-                            h->S);
-  } catch (const std::bad_alloc&) {
-    return GSLS_ERROR_ALLOCATION;
+  if (rp.reorder) {
+    const int flag = reanalyse(h, rp.order, nullptr);
+    if (flag < 0) return flag;
   }
-  if (flag < 0) return flag;
-  fill_from_symbolic(h->S, &h->last);
-  h->last.factor_bytes = 8 * h->S.loff[h->S.nnodes] + 16 * int64_t(h->S.n);
+  h->tpp_dirty = true;
   return gsls_shard(handle, nranks, rank, xchg_factor_elems, xchg_solve_elems);
 }
 
@@ -992,6 +1118,18 @@ int gsls_refine_order_dev(void* handle, const double* d_val, gsls_inform* inform
   else *inform = h->last;
   DeviceGuard g(h->device);
   const int rf = refine_order_with_values(h, d_val, true, inform);
+  inform->flag = rf;
+  return rf;
+}
+
+// the same with the values in host memory (needs no device: the refinement is host integer work)
+int gsls_refine_order(void* handle, const double* val, gsls_inform* inform) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !val) return GSLS_ERROR_CALL_SEQUENCE;
+  gsls_inform local = h->last;
+  if (!inform) inform = &local;
+  else *inform = h->last;
+  const int rf = refine_order_with_values(h, val, false, inform);
   inform->flag = rf;
   return rf;
 }

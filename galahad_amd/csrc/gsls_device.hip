@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256, LDL ? (GEMM ? 2 : 3) : 1)
 k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
             double* __restrict__ L, double* __restrict__ Linv, double* __restrict__ D,
             int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
-            double small, double u, int ldq_arg, int nrt_arg) {
+            double small, double u, int ldq_arg, int nrt_arg, const uint8_t* __restrict__ tppflag) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR, CK>& sg = *reinterpret_cast<Stage<PR, CK>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);  // [NB][LDQ], overlays the staging buffers after the GEMM
@@ -342,6 +342,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   }
 
   const PanelTask t = tasks[blockIdx.x];
+  if (LDL && tppflag[t.node]) return;     // the whole front goes through k_front_tpp
   const NodeDesc nd = nodes[t.node];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -431,11 +432,15 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
       if (LDL && want2 && j < 15 && jb + j + 1 < w) {
         const double a11 = readlane_f64(v[j], j), a21 = readlane_f64(v[j], j + 1);
         const double a22 = readlane_f64(v[j + 1], j + 1);
-        // acceptance and inverse as in block_ldlt.hxx:210-240 (test_2x2 / the scaled determinant)
-        if (!(fabs(a21) >= small)) { bad = true; why |= 8; }
-        const double detscale = 1.0 / fabs(a21);
-        const double detpiv = (a11 * detscale) * a22 - fabs(a21);
-        if (!(fabs(detpiv) >= fabs(a21) / 2)) { bad = true; why |= 8; }
+        // a hinted pair was chosen by one of the pivoting kernels before: accepted unless its determinant
+        // cancels (test_2x2 of ldlt_tpp.cxx:99-118, the weaker of the reference's two 2x2 tests; the
+        // multipliers are tested below like every other pivot's)
+        const double maxpiv = fmax(fabs(a11), fmax(fabs(a21), fabs(a22)));
+        if (!(maxpiv >= small)) { bad = true; why |= 8; }
+        const double detscale = 1.0 / maxpiv;
+        const double detpiv0 = (a11 * detscale) * a22, detpiv1 = (a21 * detscale) * a21;
+        const double detpiv = detpiv0 - detpiv1;
+        if (!(fabs(detpiv) >= fmax(small, fmax(fabs(detpiv0 / 2), fabs(detpiv1 / 2))))) { bad = true; why |= 8; }
         const double d11 = (a22 * detscale) / detpiv, d22 = (a11 * detscale) / detpiv;
         const double d21 = (-a21 * detscale) / detpiv;
         const double own1 = d11 * v[j] + d21 * v[j + 1], own2 = d21 * v[j] + d22 * v[j + 1];
@@ -766,7 +771,7 @@ __global__ void __launch_bounds__(256)
 k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
             double* __restrict__ L, double* __restrict__ D, int32_t* __restrict__ gperm,
             int32_t* __restrict__ stat, int32_t* __restrict__ faillist, const int32_t* __restrict__ fastok,
-            double small, double u) {
+            double small, double u, const uint8_t* __restrict__ tppflag) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<PR>& sg = *reinterpret_cast<Stage<PR>*>(smem_raw);
   double* P = reinterpret_cast<double*>(smem_raw);
@@ -777,6 +782,7 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
   __shared__ int32_t lperm[NB];
 
   const PanelTask t = tasks[blockIdx.x];
+  if (tppflag[t.node]) return;               // the whole front goes through k_front_tpp
   const NodeDesc nd = nodes[t.node];
   if (fastok[nd.iblk + t.step]) return;      // the optimistic pass (k_diag_fast<true>) already did this block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1074,6 +1080,251 @@ k_diag_ldlt(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 }
 
 // =================================================================================================
+// Threshold partial pivoting over a WHOLE front -- the fallback that always terminates.  The blocked
+// kernels above search for pivots inside one 64-column block only; a front whose pivots need partners
+// from another block (K = [0 B; B^T 0]: every elimination is a 2x2 pivot) is flagged by the host and comes
+// here instead: ONE workgroup per front, right-looking, in global memory, pivot search across all of the
+// front's fully summed columns.  Behavioural model: ldlt_tpp_factor (ssids/cpu/kernels/ldlt_tpp.cxx:140-240;
+// candidate order, test_2x2 :99-130, the 1x1 threshold test and the zero-column handling are restated 1:1),
+// called by the reference on the columns its blocked APP kernel could not eliminate (factor.hxx:74-106).
+// Columns that still fail are delayed: reported in faillist (the host moves them to the parent front,
+// gsls_api.cpp), except at a root front (m == n: nothing is left to wait for), where they are recorded as zero
+// pivots like the reference's delays out of a root.  Not a fast kernel: it runs on the few fronts that need it.
+// The n x n pivot block is mirrored to full symmetric storage first (the rectangle has the room), so that
+// a column's entries are contiguous whichever side of the diagonal they lie on.
+// =================================================================================================
+__device__ __forceinline__ void tpp_sync() {
+  __threadfence_block();
+  __syncthreads();
+}
+// block-wide max |.| (every thread gets the result)
+__device__ __forceinline__ double tpp_max(double v, double* redv) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) redv[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(redv[0], redv[1]), fmax(redv[2], redv[3]));
+}
+// block-wide (max, smallest index attaining it)
+__device__ __forceinline__ void tpp_argmax(double& v, int& i, double* redv, int* redi) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(i, o);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = i; }
+  __syncthreads();
+  v = redv[0]; i = redi[0];
+  for (int k = 1; k < 4; ++k)
+    if (redv[k] > v || (redv[k] == v && redi[k] < i)) { v = redv[k]; i = redi[k]; }
+}
+
+__global__ void __launch_bounds__(256)
+k_front_tpp(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list, double* __restrict__ L,
+            double* __restrict__ D, int32_t* __restrict__ gperm, int32_t* __restrict__ stat,
+            int32_t* __restrict__ faillist, double small, double u, int nnodes) {
+  __shared__ double redv[8];
+  __shared__ int redi[4];
+  __shared__ int cnt[3];
+  const NodeDesc nd = nodes[list[blockIdx.x]];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = nd.m, n = nd.n;
+  const int64_t ld = nd.ld;
+  double* A = L + nd.loff;
+  double* Dn = D + 2 * int64_t(nd.sptr);
+  int32_t* pm = gperm + nd.sptr;
+  const bool root = (nd.parent >= nnodes) || (m == n);
+  if (tid < 3) cnt[tid] = 0;
+  // full symmetric storage of the pivot block
+  for (int c = wave; c < n; c += 4)
+    for (int i = lane; i < c; i += 64) A[c * ld + i] = A[i * ld + c];
+  tpp_sync();
+
+  // symmetric swap of positions x < y of the trailing matrix (rows of the finished columns follow)
+  auto swap_sym = [&](int x, int y, int p) {
+    if (x == y) return;           // uniform
+    if (y < x) { const int t = x; x = y; y = t; }
+    for (int c = tid; c < n; c += 256) {
+      const double a = A[c * ld + x], b = A[c * ld + y];
+      A[c * ld + x] = b;
+      A[c * ld + y] = a;
+    }
+    tpp_sync();
+    for (int i = p + tid; i < m; i += 256) {
+      const double a = A[x * ld + i], b = A[y * ld + i];
+      A[x * ld + i] = b;
+      A[y * ld + i] = a;
+    }
+    if (tid == 0) { const int t = pm[x]; pm[x] = pm[y]; pm[y] = t; }
+    tpp_sync();
+  };
+  // column p has no entry of size `small` or more: a zero pivot (ldlt_tpp.cxx:150-160)
+  auto zero_pivot = [&](int p) {
+    for (int i = p + tid; i < m; i += 256) A[p * ld + i] = (i == p) ? 1.0 : 0.0;
+    if (tid == 0) { Dn[2 * p] = 0.0; Dn[2 * p + 1] = 0.0; }
+    tpp_sync();
+  };
+  auto pivot_1x1 = [&](int p) {
+    const double app = A[p * ld + p];
+    const double d = 1.0 / app;
+    for (int c = p + 1 + wave; c < n; c += 4) {
+      const double acp = A[p * ld + c];
+      for (int i = p + 1 + lane; i < m; i += 64) A[c * ld + i] -= (A[p * ld + i] * acp) * d;
+    }
+    tpp_sync();
+    for (int i = p + tid; i < m; i += 256) A[p * ld + i] = (i == p) ? 1.0 : A[p * ld + i] * d;
+    if (tid == 0) { Dn[2 * p] = d; Dn[2 * p + 1] = 0.0; }
+    tpp_sync();
+  };
+  auto pivot_2x2 = [&](int p, double d11, double d21, double d22) {
+    for (int c = p + 2 + wave; c < n; c += 4) {
+      const double a1c = A[p * ld + c], a2c = A[(p + 1) * ld + c];
+      for (int i = p + 2 + lane; i < m; i += 64) {
+        const double a1i = A[p * ld + i], a2i = A[(p + 1) * ld + i];
+        A[c * ld + i] -= d11 * (a1i * a1c) + d21 * (a2i * a1c + a1i * a2c) + d22 * (a2i * a2c);
+      }
+    }
+    tpp_sync();
+    for (int i = p + tid; i < m; i += 256) {
+      const double a1 = A[p * ld + i], a2 = A[(p + 1) * ld + i];
+      A[p * ld + i] = (i == p) ? 1.0 : ((i == p + 1) ? 0.0 : d11 * a1 + d21 * a2);
+      A[(p + 1) * ld + i] = (i == p) ? 0.0 : ((i == p + 1) ? 1.0 : d21 * a1 + d22 * a2);
+    }
+    if (tid == 0) { Dn[2 * p] = d11; Dn[2 * p + 1] = d21; Dn[2 * p + 2] = INFINITY; Dn[2 * p + 3] = d22; }
+    tpp_sync();
+  };
+  // max |A(i, col)| over rows [from, m) except rows x1, x2
+  auto col_max_excl = [&](int col, int from, int x1, int x2) -> double {
+    double v = 0.0;
+    for (int i = from + tid; i < m; i += 256)
+      if (i != x1 && i != x2) v = fmax(v, fabs(A[col * ld + i]));
+    return tpp_max(v, redv);
+  };
+
+  int p = 0;
+  while (p < n) {
+    if (col_max_excl(p, p, -1, -1) < small) { zero_pivot(p); ++p; continue; }
+    bool found = false;
+    for (int q = p + 1; q < n && !found; ++q) {
+      // column q: largest entry overall (negligible column?) and the largest one among the rows [p, q)
+      double mall = 0.0, mv = -1.0;
+      int mi = INT_MAX;
+      for (int i = p + tid; i < m; i += 256) {
+        const double a = fabs(A[q * ld + i]);
+        mall = fmax(mall, a);
+        if (i < q && (a > mv || (a == mv && i < mi))) { mv = a; mi = i; }
+      }
+      mall = tpp_max(mall, redv);
+      if (mall < small) {
+        swap_sym(p, q, p);
+        zero_pivot(p);
+        ++p;
+        found = true;
+        break;
+      }
+      tpp_argmax(mv, mi, redv + 4, redi);
+      const int t = mi;
+      const double maxt = col_max_excl(t, p, t, q);
+      double maxq = col_max_excl(q, p, q, t);
+      const double a11 = A[t * ld + t], a21 = A[t * ld + q], a22 = A[q * ld + q];
+      // test_2x2 (ldlt_tpp.cxx:99-130)
+      bool ok2 = false;
+      double d11 = 0.0, d21 = 0.0, d22 = 0.0;
+      const double maxpiv = fmax(fabs(a11), fmax(fabs(a21), fabs(a22)));
+      if (maxpiv >= small) {
+        const double detscale = 1.0 / maxpiv;
+        const double detpiv0 = (a11 * detscale) * a22, detpiv1 = (a21 * detscale) * a21;
+        const double detpiv = detpiv0 - detpiv1;
+        if (!(fabs(detpiv) < fmax(small, fmax(fabs(detpiv0 / 2), fabs(detpiv1 / 2))))) {
+          d11 = (a22 * detscale) / detpiv;
+          d21 = (-a21 * detscale) / detpiv;
+          d22 = (a11 * detscale) / detpiv;
+          if (fmax(maxq, maxt) < small) ok2 = true;
+          else {
+            const double x1 = fabs(d11) * maxt + fabs(d21) * maxq;
+            const double x2 = fabs(d21) * maxt + fabs(d22) * maxq;
+            ok2 = (u * fmax(x1, x2) < 1.0);
+          }
+        }
+      }
+      if (ok2) {
+        swap_sym(t, p, p);
+        swap_sym(q, p + 1, p);
+        pivot_2x2(p, d11, d21, d22);
+        p += 2;
+        found = true;
+        break;
+      }
+      maxq = fmax(maxq, fabs(a21));
+      if (fabs(a22) >= u * maxq && fabs(a22) >= small) {
+        swap_sym(q, p, p);
+        pivot_1x1(p);
+        p += 1;
+        found = true;
+        break;
+      }
+    }
+    if (found) continue;
+    // last resort: column p itself as a 1x1 pivot
+    const double maxp = col_max_excl(p, p, p, -1);
+    const double app = A[p * ld + p];
+    if (fabs(app) >= u * maxp && fabs(app) >= small) {
+      pivot_1x1(p);
+      ++p;
+    } else {
+      break;                      // no more pivots in this front
+    }
+  }
+  const int nelim = p;
+  if (nelim < n && root) {          // nowhere to delay to: zero pivots (cf. delays out of a root, factor.hxx:118-119)
+    for (int c = nelim; c < n; ++c) zero_pivot(c);
+  }
+  const int ndone = (nelim < n && !root) ? nelim : n;
+  // inertia of what was eliminated
+  {
+    int nneg = 0, ntwo = 0, nzero = 0;
+    for (int i = tid; i < ndone; i += 256) {
+      const double a11 = Dn[2 * i];
+      if (isinf(a11)) continue;                                   // second half of a 2x2 pivot
+      if (i + 1 < ndone && isinf(Dn[2 * i + 2])) {
+        const double a21 = Dn[2 * i + 1], a22 = Dn[2 * i + 3];
+        ++ntwo;
+        const double det = a11 * a22 - a21 * a21, tr = a11 + a22;
+        if (det < 0) nneg += 1;
+        else if (tr < 0) nneg += 2;
+      } else {
+        if (a11 == 0.0) ++nzero;
+        if (a11 < 0.0) ++nneg;
+      }
+    }
+    if (nneg) atomicAdd(&cnt[0], nneg);
+    if (ntwo) atomicAdd(&cnt[1], ntwo);
+    if (nzero) atomicAdd(&cnt[2], nzero);
+    __syncthreads();
+    if (tid == 0) {
+      if (cnt[2]) atomicAdd(&stat[1], cnt[2]);
+      if (cnt[0]) atomicAdd(&stat[2], cnt[0]);
+      if (cnt[1]) atomicAdd(&stat[3], cnt[1]);
+      atomicAdd(&stat[14], 1);
+      if (ndone < n) {
+        atomicAdd(&stat[4], n - ndone);
+        atomicAdd(&stat[15], n - ndone);
+      }
+    }
+  }
+  if (ndone < n) {
+    for (int j = ndone + tid; j < n; j += 256) {
+      const int slot = atomicAdd(&stat[5], 1);
+      if (slot < FAILCAP) faillist[slot] = pm[j];
+    }
+  }
+  // the rectangle's upper triangle is nobody's input: leave it clean
+  for (int c = 1 + wave; c < n; c += 4)
+    for (int i = lane; i < c; i += 64) A[c * ld + i] = 0.0;
+}
+
+// =================================================================================================
 // panel kernel: row chunk c>=1 of block column `step`:  rows [kb+128+(c-1)*64, +64)
 //   R = (A - L[rows,0:kb] D L[kb:kb+w,0:kb]^T) * L11^-T * D11^-1
 // =================================================================================================
@@ -1083,7 +1334,7 @@ template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         double* __restrict__ L, const double* __restrict__ D, const int32_t* __restrict__ gperm,
-        int32_t* __restrict__ stat, int32_t* __restrict__ faillist, double u) {
+        int32_t* __restrict__ stat, int32_t* __restrict__ faillist, double u, const uint8_t* __restrict__ tppflag) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
   double* Pc = reinterpret_cast<double*>(smem_raw);                  // [w][RBP]
@@ -1092,6 +1343,7 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
   __shared__ int32_t lp[NB];
 
   const PanelTask t = tasks[blockIdx.x];
+  if (!POSDEF && tppflag[t.node]) return;
   const NodeDesc nd = nodes[t.node];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kb = t.step * NB;
@@ -2235,7 +2487,7 @@ void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.tftasks, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.posowner};
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.posowner, F.tppflag, F.tpplist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -2582,6 +2834,8 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tinyskip), std::max(nn, 1)));
   HIPCHK(hipMemsetAsync(F.tinyskip, 0, std::max(nn, 1), st));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tinyfail), FAILCAP * sizeof(int32_t)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tppflag), std::max(nn, 1)));
+  HIPCHK(hipMemsetAsync(F.tppflag, 0, std::max(nn, 1), st));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.hint), std::max(S.n, 1)));
   HIPCHK(hipMemsetAsync(F.hint, 0, std::max(S.n, 1), st));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
@@ -2591,7 +2845,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
 // -------------------------------------------------------------------------------------------------
 template <bool POSDEF>
 static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::vector<LevelPlan>& plan,
-                                double small, double u, hipStream_t st) {
+                                double small, double u, hipStream_t st, int which = 0) {
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
   const size_t lds_chol = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * NB);
@@ -2602,6 +2856,9 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
       hipLaunchKernelGGL(k_assemble_pull, dim3(lp.pull_cnt), dim3(256), 0, st,
                          static_cast<const PullTask*>(F.pulltasks) + lp.pull_begin,
                          static_cast<const PullSeg*>(F.pullsegs), F.cmap, F.L, F.C);
+    if (!POSDEF && !F.tpp_cnt[which].empty() && F.tpp_cnt[which][l] > 0)   // fronts flagged for whole-front pivoting
+      hipLaunchKernelGGL(k_front_tpp, dim3(F.tpp_cnt[which][l]), dim3(256), 0, st, F.nodes,
+                         F.tpplist + F.tpp_begin[which][l], F.L, F.D, F.gperm, F.stat, F.faillist, small, u, S.nnodes);
     if (!POSDEF && lp.tf_cnt > 0)   // only in the tiny-front plan (planT)
       hipLaunchKernelGGL(k_front_tiny, dim3((lp.tf_cnt + 3) / 4), dim3(256), 0, st,
                          static_cast<const TinyFrontTask*>(F.tftasks) + lp.tf_begin, lp.tf_cnt, F.L, F.D, F.C,
@@ -2612,7 +2869,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
         if (POSDEF) {
           hipLaunchKernelGGL((k_diag_fast<false, true>), dim3(lp.panel_cnt[2 * s]), dim3(256), lds_chol, st, F.nodes,
                              F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u,
-                             LDQ, PRX / 16);
+                             LDQ, PRX / 16, F.tppflag);
         } else {
           // the LDS panel is as tall as this launch's tallest front: small fronts share a CU
           const int nrt = std::max(NB / 16, (lp.panel_rows[s] + 15) / 16);
@@ -2621,14 +2878,14 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
           if (s == 0)
             hipLaunchKernelGGL((k_diag_fast<true, false>), dim3(lp.panel_cnt[2 * s]), dim3(256), lds_fldl, st, F.nodes,
                                F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u,
-                               ldq, nrt);
+                               ldq, nrt, F.tppflag);
           else
             hipLaunchKernelGGL((k_diag_fast<true, true>), dim3(lp.panel_cnt[2 * s]), dim3(256), lds_fldl, st, F.nodes,
                                F.ptasks + lp.panel_begin[2 * s], F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u,
-                               ldq, nrt);
+                               ldq, nrt, F.tppflag);
           hipLaunchKernelGGL(k_diag_ldlt, dim3(lp.panel_cnt[2 * s]), dim3(256), lds_diag, st, F.nodes,
                              F.ptasks + lp.panel_begin[2 * s], F.L, F.D, F.gperm, F.stat, F.faillist, F.fastok,
-                             small, u);
+                             small, u, F.tppflag);
         }
       }
       if (lp.panel_cnt[2 * s + 1] > 0) {
@@ -2637,7 +2894,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
                              F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.Linv);
         else
           hipLaunchKernelGGL(k_panel<false>, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_panel, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u);
+                             F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u, F.tppflag);
       }
     }
     if (!POSDEF && &plan == &F.planT && l < int(F.bl_level.size()) && F.bl_level[l].np > 0) {
@@ -2647,9 +2904,9 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
       const int ldq = (16 * nrt) % 32 == 16 ? 16 * nrt : 16 * nrt + 16;
       const size_t lds_fldl = sizeof(double) * ldq * (NB + 16);
       hipLaunchKernelGGL((k_diag_fast<true, false>), dim3(b.np), dim3(256), lds_fldl, st, F.nodes,
-                         F.bl_ptasks + b.pbeg, F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u, ldq, nrt);
+                         F.bl_ptasks + b.pbeg, F.L, F.Linv, F.D, F.stat, F.fastok, F.hint, small, u, ldq, nrt, F.tppflag);
       hipLaunchKernelGGL(k_diag_ldlt, dim3(b.np), dim3(256), lds_diag, st, F.nodes, F.bl_ptasks + b.pbeg, F.L, F.D,
-                         F.gperm, F.stat, F.faillist, F.fastok, small, u);
+                         F.gperm, F.stat, F.faillist, F.fastok, small, u, F.tppflag);
       if (b.nt > 0)
         hipLaunchKernelGGL(k_contrib<false>, dim3(b.nt), dim3(256), 0, st, F.nodes, F.bl_ttasks + b.tbeg, F.L, F.D,
                            F.C);
@@ -2714,6 +2971,36 @@ hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std:
     F.bl_tctasks = d;
   }
   HIPCHK(hipMemcpyAsync(F.tinyskip, skip.data(), skip.size(), hipMemcpyHostToDevice, st));
+  return hipStreamSynchronize(st);
+}
+
+// Fronts that go through k_front_tpp instead of the blocked kernels (host decision, gsls_api.cpp): a flag per
+// node for the blocked kernels to skip them, and per level one node list per plan kind (0: all, 1: the
+// subtrees this rank owns, 2: the top part).
+hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st) {
+  const int nn = S.nnodes;
+  std::vector<uint8_t> flag(std::max(nn, 1), 0);
+  for (int s : nodes) flag[s] = 1;
+  std::vector<int32_t> list;
+  for (int which = 0; which < 3; ++which) {
+    F.tpp_begin[which].assign(S.nlevels, 0);
+    F.tpp_cnt[which].assign(S.nlevels, 0);
+    if (nodes.empty()) { F.tpp_cnt[which].clear(); continue; }
+    for (int l = 0; l < S.nlevels; ++l) {
+      F.tpp_begin[which][l] = int(list.size());
+      for (int i = S.lvlptr[l]; i < S.lvlptr[l + 1]; ++i) {
+        const int s = S.lvlnodes[i];
+        if (!flag[s]) continue;
+        const bool mine = which == 0 || (F.sharded && (which == 1 ? S.owner[s] == F.myrank : S.owner[s] < 0));
+        if (mine) list.push_back(s);
+      }
+      F.tpp_cnt[which][l] = int(list.size()) - F.tpp_begin[which][l];
+    }
+  }
+  if (F.tpplist) (void)hipFree(F.tpplist);
+  F.tpplist = nullptr;
+  HIPCHK(upload(F.tpplist, list, st));
+  HIPCHK(hipMemcpyAsync(F.tppflag, flag.data(), flag.size(), hipMemcpyHostToDevice, st));
   return hipStreamSynchronize(st);
 }
 
@@ -2896,15 +3183,15 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
                          static_cast<const double*>(nullptr), F.arow, F.acol, F.invp);
     }
     if (posdef) HIPCHK(ensure_linv(F));
-    hipError_t e = posdef ? factor_levels<true>(S, F, F.planA, small, u, st)
-                          : factor_levels<false>(S, F, F.planA, small, u, st);
+    hipError_t e = posdef ? factor_levels<true>(S, F, F.planA, small, u, st, 1)
+                          : factor_levels<false>(S, F, F.planA, small, u, st, 1);
     if (e != hipSuccess) return e;
     launch_segments(F, F.segC, F.C, d_xchg, 0, st);
   } else if (phase == 2) {
     if (F.myrank != 0) return hipSuccess;
     launch_segments(F, F.segC, F.C, d_xchg, 1, st);
-    return posdef ? factor_levels<true>(S, F, F.planB, small, u, st)
-                  : factor_levels<false>(S, F, F.planB, small, u, st);
+    return posdef ? factor_levels<true>(S, F, F.planB, small, u, st, 2)
+                  : factor_levels<false>(S, F, F.planB, small, u, st, 2);
   } else {
     return hipErrorInvalidValue;
   }

@@ -75,6 +75,9 @@ struct DeviceFactor {
   void* tftasks = nullptr;
   uint8_t* tinyskip = nullptr;     // per node: 1 = not for k_front_tiny (blacklisted)
   int32_t* tinyfail = nullptr;     // nodes k_front_tiny gave up on in the last pass (count in stat[13])
+  uint8_t* tppflag = nullptr;      // per node: 1 = factorized by k_front_tpp (pivot search across the whole front)
+  int32_t* tpplist = nullptr;      // ... those nodes, per plan kind and level
+  std::vector<int> tpp_begin[3], tpp_cnt[3];
   PanelTask* bl_ptasks = nullptr;
   TileTask* bl_ttasks = nullptr;
   void* bl_tctasks = nullptr;
@@ -136,6 +139,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
 void dev_free(DeviceFactor& F);
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
                       const double* d_scale, double small, double u, hipStream_t st, bool use_tiny = false);
+hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
 hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);

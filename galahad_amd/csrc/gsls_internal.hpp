@@ -52,8 +52,9 @@ struct Symbolic {
 };
 
 // returns a GSLS_* flag (0 ok, GSLS_ERROR_ORDER, GSLS_WARNING_ANAL_SINGULAR, ...)
+// force_var (n flags by variable, may be null): variables that must share a supernode with their parent column
 int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* order, int ordering,
-                     int nemin, Symbolic& S);
+                     int nemin, Symbolic& S, const uint8_t* force_var = nullptr);
 
 // fill-reducing ordering (nested dissection on the graph of A); writes perm[var] = position (0-based)
 void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow,

@@ -160,8 +160,13 @@ struct Supernodes {
 // feed the parent's own columns -- could no longer overlap with the child's: for nested dissection
 // that doubles the number of dependent pivots on the critical path (child separator + parent
 // separator at every level instead of one).
+// force (may be null): columns that MUST share a supernode with their parent column, whatever the
+// amalgamation rules say -- delayed pivots that have to meet the pivot candidates of the front they were
+// moved to (gsls_api.cpp: plan_repair).  Always structurally valid: a child's rows are a subset of its
+// parent's; the merged front just carries explicit zeros.
 void relaxed_supernodes(int n, int realn, const std::vector<int>& parent,
-                        const std::vector<int>& cc, int nemin, bool keep_branches, Supernodes& out) {
+                        const std::vector<int>& cc, int nemin, bool keep_branches, const std::vector<char>* force,
+                        Supernodes& out) {
   const int64_t kNever = INT64_MAX;
   std::vector<int> nelim(n + 1, 1), nvert(n + 1, 1), mhead(n + 1, -1), mnext(n + 1, -1);
   std::vector<int64_t> ezero(n + 1, 0);
@@ -189,7 +194,7 @@ void relaxed_supernodes(int n, int realn, const std::vector<int>& parent,
       bool merge = false;
       if (ezero[par] != kNever)
         merge = (cc[par] == cc[c] - 1 && nelim[par] == 1 && big_kids < 2) ||
-                (nelim[par] < nemin && nelim[c] < nemin);
+                (nelim[par] < nemin && nelim[c] < nemin) || (force && (*force)[c]);
       if (merge) {
         mnext[c] = mhead[par];
         mhead[par] = c;
@@ -237,7 +242,7 @@ void relaxed_supernodes(int n, int realn, const std::vector<int>& parent,
 }  // namespace
 
 int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* order, int ordering,
-                     int nemin, Symbolic& S) {
+                     int nemin, Symbolic& S, const uint8_t* force_var) {
   S = Symbolic();
   S.n = n;
   if (nemin < 1) nemin = 32;
@@ -273,7 +278,12 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
   if (S.realn != n) flag = GSLS_WARNING_ANAL_SINGULAR;
   column_counts(n, aptr, arow, S.perm, S.invp, parent, cc);
   Supernodes sn;
-  relaxed_supernodes(n, S.realn, parent, cc, nemin, ordering != GSLS_ORDER_USER, sn);
+  std::vector<char> forcecol;
+  if (force_var) {
+    forcecol.assign(n + 1, 0);
+    for (int p = 0; p < n; ++p) forcecol[p] = force_var[S.invp[p]] ? 1 : 0;
+  }
+  relaxed_supernodes(n, S.realn, parent, cc, nemin, ordering != GSLS_ORDER_USER, force_var ? &forcecol : nullptr, sn);
 
   // final pivot order = supernode renumbering applied on top of the postorder
   {

@@ -219,6 +219,8 @@ int gsls_get_order(void* handle, int32_t* order);
  * gsls_factor[_dev] does this itself on the first indefinite factorization; multi-GPU callers call it on every rank
  * before gsls_shard (the partition depends on the order).  No reference counterpart: SSIDS delays pivots instead. */
 int gsls_refine_order_dev(void* handle, const double* d_val, gsls_inform* inform);
+/* the same with `val` in host memory; needs no device */
+int gsls_refine_order(void* handle, const double* val, gsls_inform* inform);
 
 /* how the last LDL^T factorization went ("optimistic pass"): blocks / tiny fronts that passed the
  * optimistic kernels, blocks redone by the complete-pivoting kernel, tiny fronts kept off the wave-per-front kernel */

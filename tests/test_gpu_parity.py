@@ -439,15 +439,16 @@ def test_factor_with_scaling_vector(posdef):
     s.terminate()
 
 
-def test_all_zero_diagonal_saddle_needs_2x2_everywhere():
+@pytest.mark.parametrize("nb", [500, 700, 2500])
+def test_all_zero_diagonal_saddle_needs_2x2_everywhere(nb):
     """K = [0 B; B^T 0]: no variable has a pivot of its own, every elimination is a 2x2 pivot.  The backend
-    pairs each variable with its strongest neighbour when the values arrive (so that partners share a
-    diagonal block) and keeps pairs together when a block boundary splits them; inertia (k, k, 0).
-    (Not every such matrix converges yet: pairs whose multipliers fail the threshold test below their block can
-    send the order repair into a cycle -- DESIGN.md, what comes next.)"""
+    pairs each variable with its strongest neighbour when the values arrive (partners share a supernode) and, where
+    the 64-column blocked kernels still cannot place a pivot, falls back to threshold partial pivoting over the
+    whole front (k_front_tpp) and to delays towards the root (gsls_api.cpp: plan_repair); inertia (k, k, 0).
+    nb = 700 is the instance that ended with flag -98 in round 1 (order-repair cycle); nb = 2500 is the
+    5000-variable case."""
     from galahad_amd import SLS, SMT, Control, InformSLS
     rng = np.random.default_rng(1)
-    nb = 500
     n = 2 * nb
     r, c, v = [], [], []
     for i in range(nb):
@@ -469,5 +470,5 @@ def test_all_zero_diagonal_saddle_needs_2x2_everywhere():
         assert i.negative_eigenvalues == nb and i.rank == n and i.two_by_two_pivots > 0
         x = s.solve(m, rhs, ct, i)
         assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-12
-    assert i.delayed_pivots == 0          # the repaired order is remembered
+    assert i.delayed_pivots == 0          # the repaired order (and the fronts that need whole-front pivoting) are remembered
     s.terminate()
