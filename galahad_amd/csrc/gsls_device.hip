@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "gsls_device.hpp"
@@ -641,12 +642,14 @@ struct TinyFrontTask {
   int32_t n, m, ld, sptr;
   int64_t loff, coff;
   int32_t iblk, has_contrib, node, pad;
+  int64_t lfoff, lboff;      // wave tier: the front's packed images (k_front_tiny writes them instead of the rectangle)
 };
 __global__ void __launch_bounds__(256)
 k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restrict__ L,
              double* __restrict__ D, double* __restrict__ C, int32_t* __restrict__ stat,
              int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
-             const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u) {
+             const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u,
+             double* __restrict__ Lf, double* __restrict__ Lbk) {
   __shared__ double psh[4][2 * 32];   // per wave: the pivots d_k (for L*D)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ti = blockIdx.x * 4 + wave;
@@ -700,9 +703,31 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
     return;
   }
   // ---- factors out: column k of L (rows k..m-1), D, statistics ----------------------------------------
+  if (Lf && t.lfoff >= 0) {
+    // wave tier: straight into the two packed images the solves read (layout: "WAVE TIER" below); nothing
+    // reads the rectangle of such a front again
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    double2_t* f = reinterpret_cast<double2_t*>(Lf + t.lfoff);
 #pragma unroll
-  for (int k = 0; k < 32; ++k)
-    if (k < n && lane >= k && lane < m) Lb[int64_t(k) * t.ld + lane] = v[k];
+    for (int j = 0; j < 16; ++j) {
+      const int r0 = 2 * j + 1;
+      if (2 * j < n && lane >= r0 && lane < m) {
+        double2_t e;
+        e.x = v[2 * j];
+        e.y = (lane > r0 && r0 < n) ? v[2 * j + 1] : 0.0;
+        f[j * (m - 1) - j * (j - 1) + lane - r0] = e;
+      }
+    }
+    const int ri = lane >> 1, q = n >> 1;
+    double* bk = Lbk + t.lboff + 2 * ((ri <= q) ? ri * ri : q * q + (ri - q) * n) + (lane & 1);
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (k < n && lane > k && lane < m) bk[2 * k] = v[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (k < n && lane >= k && lane < m) Lb[int64_t(k) * t.ld + lane] = v[k];
+  }
   if (lane < n) {
     D[2 * int64_t(t.sptr + lane)] = myd0;
     D[2 * int64_t(t.sptr + lane) + 1] = myd1;
@@ -1891,8 +1916,8 @@ __global__ void k_solve_diag(int n, const double* __restrict__ D, const int32_t*
     const int gj = gperm[i + 1];
     const double d21 = D[2 * int64_t(i) + 1], d22 = D[2 * int64_t(i) + 3];
     const double x1 = xp[gi], x2 = xp[gj];
-    xp[gi] = d0 * x1 + d21 * x2;
-    xp[gj] = d21 * x1 + d22 * x2;
+    xp[gi] = fma(d0, x1, d21 * x2);
+    xp[gj] = fma(d21, x1, d22 * x2);
   } else {
     xp[gi] *= d0;
   }
@@ -2207,10 +2232,10 @@ k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* 
   // child order (host-built gather lists: fixed summation order, and a front with hundreds of children
   // costs one round trip, not one per child)
   for (int i = lane; i < m; i += 64) {
-    double acc0 = (i < n) ? xp[nd.sptr + i] : 0.0;
+    double csum = 0.0;                  // contributions first, then the right-hand side (the wave tier's order)
     const int g0 = gth_ptr[nd.goff + i], g1 = gth_ptr[nd.goff + i + 1];
-    for (int g = g0; g < g1; ++g) acc0 += cvec[gth_src[g]];
-    r[i] = acc0;
+    for (int g = g0; g < g1; ++g) csum += cvec[gth_src[g]];
+    r[i] = ((i < n) ? xp[nd.sptr + i] : 0.0) + csum;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   double yv = (lane < n) ? r[pslot] : 0.0;
@@ -2245,16 +2270,8 @@ k_solve_bwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* 
   double xv = (lane < n) ? xp[pslot] : 0.0;
   if (lane < cm) z[lane] = xp[rlist[nd.roff + n + lane]];
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  if (lane < n) {
-    double s0 = 0.0, s1 = 0.0;
-    int i = 0;
-    for (; i + 1 < cm; i += 2) {
-      s0 = fma(col[n + i], z[i], s0);
-      s1 = fma(col[n + i + 1], z[i + 1], s1);
-    }
-    if (i < cm) s0 = fma(col[n + i], z[i], s0);
-    xv -= s0 + s1;
-  }
+  if (lane < n)       // rows below the pivots, last to first (the order of the wave tier: same bits)
+    for (int i = cm - 1; i >= 0; --i) xv = fma(-col[n + i], z[i], xv);
 #pragma unroll
   for (int j = NMAX - 1; j >= 0; --j) {   // unit upper triangular solve, last pivot first
     const double xj = readlane_f64(xv, j);
@@ -2416,6 +2433,430 @@ k_big_bwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ t
 }
 
 // =================================================================================================
+// WAVE TIER of the LDL^T solves: fronts of at most 64 rows whose whole subtree consists of such fronts (in a
+// saddle-point tree that is every front), one WAVE per front, lane r = row r of the front, pivot rows and
+// contribution rows alike.
+//   * the factor of such a front is kept in two packed images, each in exactly the order its sweep consumes it,
+//     so every load is a 16-byte-per-lane segment of consecutive addresses and no byte that is not part of L is read:
+//       forward  image (Lf): for column pair j = (2j, 2j+1): rows r = 2j+1 .. m-1, element (L(r,2j), L(r,2j+1))
+//                            [the slot of L(2j+1,2j+1) holds 0]
+//       backward image (Lb): for row pair i = (2i, 2i+1): columns k = 0 .. min(2i, n-1), element (L(2i,k), L(2i+1,k))
+//                            [the slot of L(2i,2i) holds 0]
+//     The rectangle m x n of the factorization kernels stores 1.4x the entries of L for the typical 39 x 24 front,
+//     and walking it column by column in the backward sweep drags whole cache lines for 8 bytes each.
+//   * the schedule is by SUBTREES, not by levels (the reference's CPU code has the same idea for the same reason:
+//     SmallLeafNumericSubtree.hxx): a GROUP is a small subtree that ONE wave walks in postorder (forward) or reverse
+//     postorder (backward).  Inside a group nothing goes through memory and nothing waits for another wave: a child's
+//     contribution vector is added into its parent's accumulator in LDS (forward), a parent leaves its front's part
+//     of the solution in LDS for its children (backward), through the static child-row -> parent-row map.  The
+//     groups of one STAGE are independent (one launch); stage k+1 holds the subtrees of what remains of the tree
+//     when the groups of stages <= k are removed, and reads their roots' contribution vectors from HBM.  A
+//     saddle-point tree of 10 levels becomes 3-4 launches per sweep, and 97 % of the factor sits in stage 0.
+//   * the right-hand side is read straight from the caller's vector (x[invp[.]]) and the solution written straight
+//     back; D^-1 is applied at the end of the forward step: no separate permutation or diagonal launches.
+// Per front the arithmetic is the tiny kernels': right-hand side + (sum of the children's contributions), the
+// recurrences column by column.
+// =================================================================================================
+enum { WT_PULL = 1, WT_INT = 2, WT_PUSH = 4, WT_ZVEC = 8 };
+struct WTask {
+  int32_t m, n, sptr, flags;   // WT_PULL: children in earlier stages (gather lists); WT_INT: children in this group
+                               // (LDS accumulator); WT_PUSH: the parent is in this group; WT_ZVEC: the parent is in a
+                               // later stage of the tier (backward: it leaves its values in this front's cvec)
+  int64_t lfoff, lboff;        // element offsets of the front's images in Lf / Lb
+  int64_t roff, moff, goff;    // row list, contribution vector / child->parent map, gather lists
+  int32_t myslot, pslot;       // LDS slots (depth inside the group) of this front and of its parent
+};
+static_assert(sizeof(WTask) == 64, "WTask is loaded as one 64-byte record");
+struct WGroup {
+  int32_t tbeg, tcnt;          // tasks [tbeg, tbeg + tcnt), postorder
+};
+struct WPack {                 // per task, for the pack kernel
+  int64_t loff;
+  int32_t node, pad;
+};
+constexpr int WSLOT = 8;       // a group is at most this deep
+
+__device__ __forceinline__ int wf_pair_off(int j, int m) { return j * (m - 1) - j * (j - 1); }       // 16-byte units
+__device__ __forceinline__ int wb_pair_off(int i, int n) {
+  const int q = n >> 1;
+  return (i <= q) ? i * i : q * q + (i - q) * n;
+}
+static inline int64_t wf_size(int m, int n) { const int j = (n + 1) / 2; return 2 * (int64_t(j) * (m - 1) - int64_t(j) * (j - 1)); }   // doubles
+static inline int64_t wb_size(int m, int n) {
+  const int i = (m + 1) / 2, q = n / 2;
+  return 2 * ((i <= q) ? int64_t(i) * i : int64_t(q) * q + int64_t(i - q) * n);
+}
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+
+// D^-1 of pivot slot s applied to the forward result y (lane = slot - sptr); yp / yn: the neighbouring lanes' y.
+// Same expressions as k_solve_diag.
+__device__ __forceinline__ double wave_apply_d(const double* __restrict__ D, int64_t s, double y, double yp, double yn) {
+  const double d0 = D[2 * s], d1 = D[2 * s + 1];
+  if (isinf(d0)) return fma(D[2 * s - 1], yp, d1 * y);               // second row of a 2x2: d21 * y1 + d22 * y2
+  if (isinf(D[2 * s + 2])) return fma(d0, y, d1 * yn);               // first row:           d11 * y1 + d21 * y2
+  return y * d0;
+}
+
+// Everything a front's step needs that does not depend on other fronts of its group is loaded ONE FRONT AHEAD (while
+// the wave works on the previous front), so that what is left on the wave's critical path is the LDS hand-off and
+// the recurrence.  For that to work every such load must be ONE hop (address from the task record and the lane
+// only): vector-memory results return in order, so a dependent load inside the look-ahead would make the wave wait
+// for everything issued before it, the look-ahead included.  Hence
+//   * forward:  the right-hand side comes permuted (xp, by position); the pivots' D^-1 entries ride along;
+//   * forward -> backward: the forward result is kept by PIVOT SLOT (xs), which is how the backward step wants it;
+//   * backward: a front with children in an earlier stage scatters its part of the solution to THEIR
+//     contribution vectors (the forward gather lists read backwards), so a group root finds its ancestors' values
+//     in cvec[moff + i], not behind rlist;
+//   * backward: the variable index of every pivot slot (gvar = invp o gperm) is refreshed by each factorization.
+// The two-hop forms stay for the part solves (slotv == nullptr) and for roots below a front outside the tier.
+template <int NN>
+struct WFwdPre {
+  double2_t lp[NN / 2];
+  double rhs, d0, d1, dn, dp;
+  int pslot, prow;
+};
+
+// Branch-free on purpose: every load is issued unconditionally from a clamped (always valid) address and masked
+// afterwards.  hipcc's wait-count insertion falls back to s_waitcnt vmcnt(0) at control-flow joins, which would make
+// the wave wait for the look-ahead loads at the first conditional in the compute step; straight-line code gets exact
+// counted waits.  (The arrays indexed by sptr + lane / moff + lane carry 64 elements of padding.)
+template <int NN, bool APPLY_D>
+__device__ __forceinline__ void wave_fwd_load(const WTask& t, int lane, WFwdPre<NN>& p, const double* __restrict__ Lf,
+                                              const double* __restrict__ D, const int32_t* __restrict__ gperm,
+                                              const int32_t* __restrict__ cmap, const double* __restrict__ xp) {
+  const int m = t.m, n = t.n;
+  // the image through a buffer descriptor: lanes outside their range get an out-of-range offset and the hardware
+  // returns zeros -- two vector instructions per column pair (compare, select) instead of a dozen for 64-bit
+  // addresses and masks (these kernels are bound by instruction issue, not by HBM, until that is trimmed)
+  const int npair = (n + 1) >> 1;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double*>(Lf + t.lfoff), 0, 16 * (npair * (m - 1) - npair * (npair - 1)), 0x00020000);
+  const int oob = int(0x80000000);
+  const int v0 = (lane >= 1 && lane < m) ? (lane - 1) * 16 : oob;
+#pragma unroll
+  for (int j = 0; j < NN / 2; ++j) {
+    const bool ok = (lane >= 2 * j + 1) & (2 * j < n);
+    // element (row lane, pair j) sits at wf_pair_off(j, m) + lane - (2j + 1) = j (m - j - 2) + (lane - 1)
+    p.lp[j] = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? v0 : oob, j * (m - j - 2) * 16, 0));
+  }
+  const int64_t s = int64_t(t.sptr) + lane;
+  const bool piv = lane < n;
+  const double r = xp[s];
+  const int gp = gperm[s];
+  const int pr = cmap[t.moff + max(lane - n, 0)];
+  p.rhs = piv ? r : 0.0;
+  p.pslot = piv ? gp - t.sptr : lane;
+  p.prow = pr;
+  p.d0 = p.d1 = p.dn = p.dp = 0.0;
+  if (APPLY_D) {
+    const double d0 = D[2 * s], d1 = D[2 * s + 1], dn = D[2 * s + 2], dp = D[2 * s + 3 - 4 * (s > 0)];
+    p.d0 = d0;
+    p.d1 = d1;
+    p.dn = dn;
+    p.dp = dp;                          // D[2s - 1] (unused at s = 0)
+  }
+}
+
+// slotv != nullptr: the result goes there by pivot slot (job ALL: only the backward wave kernels read it);
+// otherwise to xp by position, like every other kernel's
+template <int NN, bool APPLY_D, bool PULLS>
+__device__ __forceinline__ void wave_fwd_compute(const WTask& t, int lane, const WFwdPre<NN>& p, double* __restrict__ acc,
+                                                 const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
+                                                 double* __restrict__ xp, double* __restrict__ slotv,
+                                                 double* __restrict__ cvec) {
+  const int m = t.m, n = t.n;
+  // analyse-time row `lane` of the front: right-hand side + (sum of the children's contributions)
+  double csum = 0.0;
+  if (PULLS && (t.flags & WT_PULL) && lane < m) {
+    const int g0 = gth_ptr[t.goff + lane], g1 = gth_ptr[t.goff + lane + 1];
+    int g = g0;
+    for (; g + 4 <= g1; g += 4) {       // four sources in flight at a time; summed in list order
+      const double c0 = cvec[gth_src[g]], c1 = cvec[gth_src[g + 1]], c2 = cvec[gth_src[g + 2]], c3 = cvec[gth_src[g + 3]];
+      csum = (((csum + c0) + c1) + c2) + c3;
+    }
+    for (; g < g1; ++g) csum += cvec[gth_src[g]];
+  }
+  if (t.flags & WT_INT) {
+    double* mine = acc + t.myslot * 64;
+    csum += mine[lane];
+    mine[lane] = 0.0;                   // ready for the next front at this depth
+  }
+  // pivot slot r holds the analyse-time row gperm[sptr + r] - sptr (numerical pivoting inside the front)
+  double x = __shfl(p.rhs + csum, p.pslot);
+#pragma unroll
+  for (int k4 = 0; k4 < NN; k4 += 4) {  // the image holds zeros from column n on: whole groups of four are skipped
+    if (k4 < 16 || k4 < n) {            // (uniform; no memory operation inside, so the waits stay counted)
+#pragma unroll
+      for (int k = k4; k < k4 + 4; ++k) {
+        const double yk = readlane_f64(x, k);
+        const double l = (k & 1) ? p.lp[k >> 1].y : p.lp[k >> 1].x;
+        x = fma(-l, yk, x);             // l = 0 for the rows up to k and for the columns from n on
+      }
+    }
+  }
+  {
+    // contribution rows: into the parent's accumulator (inside the group) or out to HBM; the other lanes add 0 to a
+    // spare slot / store to the padding behind the vector -- no branch
+    const bool crow = (lane >= n) & (lane < m);
+    const bool push = (t.flags & WT_PUSH) != 0;
+    double* a = acc + ((crow & push) ? t.pslot * 64 + p.prow : WSLOT * 64 + lane);
+    *a += (crow & push) ? x : 0.0;
+    if (!push && crow) cvec[t.moff + lane - n] = x;
+  }
+  if (APPLY_D) {                        // same expressions as k_solve_diag
+    const double yp = __shfl_up(x, 1), yn = __shfl_down(x, 1);
+    if (isinf(p.d0)) x = fma(p.dp, yp, p.d1 * x);              // second row of a 2x2: d21 * y1 + d22 * y2
+    else if (isinf(p.dn)) x = fma(p.d0, x, p.d1 * yn);         // first row:           d11 * y1 + d21 * y2
+    else x = x * p.d0;
+  }
+  if (lane < n) {
+    if (slotv) slotv[t.sptr + lane] = x;
+    else xp[t.sptr + p.pslot] = x;
+  }
+}
+
+template <int MM>
+struct WBwdPre {
+  double2_t up[MM / 2];
+  double x;
+  int pos, var, prow;
+};
+
+// FAST: the one-hop forms only (job ALL on the tier's own data; see above), branch-free like wave_fwd_load
+template <int MM, bool FAST>
+__device__ __forceinline__ void wave_bwd_load(const WTask& t, int lane, WBwdPre<MM>& p, const double* __restrict__ Lb,
+                                              const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
+                                              const int32_t* __restrict__ cmap, const int32_t* __restrict__ rlist,
+                                              const double* __restrict__ xp, const double* __restrict__ slotv,
+                                              const double* __restrict__ cvec, bool want_var) {
+  const int m = t.m, n = t.n;
+  const int nrp = (m + 1) >> 1;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double*>(Lb + t.lboff), 0, 16 * wb_pair_off(nrp, n), 0x00020000);
+  const int oob = int(0x80000000);
+  const int v0 = (lane < n) ? lane * 16 : oob;
+#pragma unroll
+  for (int i = 0; i < MM / 2; ++i) {
+    const bool ok = (lane <= 2 * i) & (2 * i < m);
+    p.up[i] = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? v0 : oob, wb_pair_off(i, n) * 16, 0));
+  }
+  const int64_t s = int64_t(t.sptr) + lane;
+  if (FAST) {
+    const bool piv = lane < n;
+    const int gp = gperm[s], gv = gvar[s], pr = cmap[t.moff + max(lane - n, 0)];
+    const double xs = slotv[s], z = cvec[t.moff + max(lane - n, 0)];
+    p.pos = gp;
+    p.var = gv;
+    p.prow = pr;
+    p.x = piv ? xs : ((lane < m) ? z : 0.0);    // inside a group the parent's values replace z (compute step)
+  } else {
+    p.pos = p.var = p.prow = 0;
+    p.x = 0.0;
+    if (lane < n) {
+      p.pos = gperm[s];
+      p.x = slotv ? slotv[s] : xp[p.pos];       // this front's part of the forward result: nobody else writes it
+      if (want_var) p.var = gvar[s];
+    } else if (lane < m) {                      // the ancestors' part of the solution
+      if (t.flags & WT_PUSH) p.prow = cmap[t.moff + lane - n];       // from the parent, through LDS
+      else if (t.flags & WT_ZVEC) p.x = cvec[t.moff + lane - n];     // scattered here by the parent (earlier launch)
+      else p.x = xp[rlist[t.roff + lane]];
+    }
+  }
+}
+
+template <int MM, bool PULLS>
+__device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const WBwdPre<MM>& p, double* __restrict__ xfull,
+                                                 const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
+                                                 double* __restrict__ xp, double* __restrict__ xout,
+                                                 const double* __restrict__ scale, double* __restrict__ cvec) {
+  const int m = t.m, n = t.n;
+  double x = p.x;
+  {
+    const bool arow = ((t.flags & WT_PUSH) != 0) & (lane >= n) & (lane < m);
+    const double xv = xfull[arow ? t.pslot * 64 + p.prow : WSLOT * 64 + lane];
+    x = arow ? xv : x;
+  }
+#pragma unroll
+  for (int j4 = MM - 4; j4 >= 0; j4 -= 4) {   // the image holds zeros from row m on: whole groups of four are skipped
+    if (j4 < 24 || j4 < m) {                  // (uniform; no memory operation inside, so the waits stay counted)
+#pragma unroll
+      for (int j = j4 + 3; j >= j4; --j) {
+        if (j == 0) continue;
+        const double xj = readlane_f64(x, j);
+        const double u = (j & 1) ? p.up[j >> 1].y : p.up[j >> 1].x;
+        x = fma(-u, xj, x);             // u = 0 for the lanes from j on and for the rows below the pivots
+      }
+    }
+  }
+  if (t.flags & WT_INT) xfull[t.myslot * 64 + lane] = x;       // for the children inside the group
+  if (PULLS && (t.flags & WT_PULL) && lane < m) {              // ... and for those of earlier stages
+    const int g0 = gth_ptr[t.goff + lane], g1 = gth_ptr[t.goff + lane + 1];
+    for (int g = g0; g < g1; ++g) cvec[gth_src[g]] = x;
+  }
+  if (lane < n) {
+    xp[p.pos] = x;
+    if (xout) xout[p.var] = (PULLS && scale) ? x * scale[p.var] : x;     // (the look-ahead kernels run unscaled)
+  }
+}
+
+__device__ __forceinline__ WTask wave_task(const WTask* __restrict__ tasks, int idx) {
+  return tasks[__builtin_amdgcn_readfirstlane(idx)];
+}
+
+// NARROW: every front of the launch has at most 32 pivot columns: the loads of the group's next front are in flight
+// while the wave works on the current one (two register sets, A and B).  Otherwise fronts of 33..64 columns are
+// among them: one at a time (two 64-column register sets do not fit).
+template <bool APPLY_D, bool NARROW>
+__global__ void __launch_bounds__(256)
+k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restrict__ tasks,
+             const double* __restrict__ Lf, const double* __restrict__ D, const int32_t* __restrict__ gperm,
+             const int32_t* __restrict__ cmap, const int32_t* __restrict__ gth_ptr,
+             const int64_t* __restrict__ gth_src, double* __restrict__ xp, double* __restrict__ slotv,
+             double* __restrict__ cvec) {
+  __shared__ double accs[4][(WSLOT + 1) * 64];    // + a spare row for the masked lanes
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (gi >= ngroup) return;
+  double* acc = accs[wave];
+#pragma unroll
+  for (int i = 0; i <= WSLOT; ++i) acc[i * 64 + lane] = 0.0;
+  const WGroup g = groups[gi];
+  const int te = g.tbeg + g.tcnt;
+  if constexpr (NARROW) {
+    // One register set: under load a round trip to HBM takes several times longer than a front's arithmetic, so a
+    // second register set (the next front's loads in flight during this front's recurrence) hides little and
+    // halves the number of waves per CU -- and it is the number of fronts in flight per CU that sets the bandwidth.
+    // What is fetched ahead is the next front's task record (scalar registers): every load of a front is then one
+    // hop behind the previous front's last instruction.
+    int ti = g.tbeg;
+    WTask ta = wave_task(tasks, ti);
+    while (true) {
+      const WTask tb = wave_task(tasks, min(ti + 1, te - 1));
+      WFwdPre<32> A;
+      wave_fwd_load<32, APPLY_D>(ta, lane, A, Lf, D, gperm, cmap, xp);
+      wave_fwd_compute<32, APPLY_D, false>(ta, lane, A, acc, gth_ptr, gth_src, xp, slotv, cvec);
+      if (++ti >= te) break;
+      ta = tb;
+    }
+  } else {
+    for (int ti = g.tbeg; ti < te; ++ti) {
+      const WTask t = wave_task(tasks, ti);
+      if (t.n <= 32) {
+        WFwdPre<32> P;
+        wave_fwd_load<32, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
+        wave_fwd_compute<32, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+      } else {
+        WFwdPre<64> P;
+        wave_fwd_load<64, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
+        wave_fwd_compute<64, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+      }
+    }
+  }
+}
+
+// NARROW: every front of the launch has at most 40 rows (two register sets, as in the forward kernel)
+template <bool NARROW>
+__global__ void __launch_bounds__(256)
+k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restrict__ tasks,
+             const double* __restrict__ Lb, const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
+             const int32_t* __restrict__ cmap, const int32_t* __restrict__ rlist, const int32_t* __restrict__ gth_ptr,
+             const int64_t* __restrict__ gth_src, double* __restrict__ xp, const double* __restrict__ slotv,
+             double* __restrict__ xout, const double* __restrict__ scale, double* __restrict__ cvec) {
+  __shared__ double xfs[4][(WSLOT + 1) * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (gi >= ngroup) return;
+  double* xfull = xfs[wave];
+  const WGroup g = groups[gi];
+  const bool wv = xout != nullptr;
+  if constexpr (NARROW) {
+    int ti = g.tbeg + g.tcnt - 1;
+    WTask ta = wave_task(tasks, ti);
+    while (true) {
+      const WTask tb = wave_task(tasks, max(ti - 1, g.tbeg));
+      WBwdPre<40> A;
+      wave_bwd_load<40, true>(ta, lane, A, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+      wave_bwd_compute<40, false>(ta, lane, A, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+      if (--ti < g.tbeg) break;
+      ta = tb;
+    }
+  } else {
+    for (int ti = g.tbeg + g.tcnt - 1; ti >= g.tbeg; --ti) {
+      const WTask t = wave_task(tasks, ti);
+      if (t.m <= 32) {
+        WBwdPre<32> P;
+        wave_bwd_load<32, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+        wave_bwd_compute<32, true>(t, lane, P, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+      } else {
+        WBwdPre<64> P;
+        wave_bwd_load<64, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+        wave_bwd_compute<64, true>(t, lane, P, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+      }
+    }
+  }
+}
+
+// gvar[slot] = variable eliminated at pivot slot `slot` (after the numerical pivoting of this factorization)
+__global__ void k_gvar(int n, const int32_t* __restrict__ gperm, const int32_t* __restrict__ invp,
+                       int32_t* __restrict__ gvar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gvar[i] = invp[gperm[i]];
+}
+
+// rectangle -> the two packed images, for the wave-tier fronts that a workgroup kernel factorized (first
+// factorizations, blacklisted fronts, fronts of more than 32 columns); k_front_tiny writes the images itself.
+// mode 0: every task; mode 1: only those k_front_tiny did not do in this pass.  One wave per front.
+__global__ void __launch_bounds__(256)
+k_wpack(const WTask* __restrict__ tasks, const WPack* __restrict__ packs, int ntask, int mode,
+        const uint8_t* __restrict__ tinyskip, const double* __restrict__ L, double* __restrict__ Lf,
+        double* __restrict__ Lb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ti = blockIdx.x * 4 + wave;
+  if (ti >= ntask) return;
+  const WTask t = wave_task(tasks, ti);
+  const WPack pk = packs[__builtin_amdgcn_readfirstlane(ti)];
+  const int m = t.m, n = t.n;
+  if (mode == 1 && n <= 32 && !tinyskip[pk.node]) return;
+  const int ld = (m + 1) & ~1;
+  const double* A = L + pk.loff;
+  double* f = Lf + t.lfoff;
+  double* bk = Lb + t.lboff;
+  const int r = lane;
+  if (r >= m) return;
+  for (int k = 0; k < n && k < r; ++k) {
+    const double v = A[int64_t(k) * ld + r];
+    const int j = k >> 1;
+    f[2 * (wf_pair_off(j, m) + r - (2 * j + 1)) + (k & 1)] = v;
+    bk[2 * (wb_pair_off(r >> 1, n) + k) + (r & 1)] = v;
+  }
+}
+
+// D solve restricted to the pivots of the fronts in `list` (one workgroup each): the fronts the wave tier does not
+// cover, when it applies D to its own fronts inside the forward step
+__global__ void __launch_bounds__(256)
+k_solve_diag_nodes(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list, const double* __restrict__ D,
+                   const int32_t* __restrict__ gperm, double* __restrict__ xp) {
+  const NodeDesc nd = nodes[list[blockIdx.x]];
+  for (int k = threadIdx.x; k < nd.n; k += 256) {
+    const int64_t i = int64_t(nd.sptr) + k;
+    const double d0 = D[2 * i];
+    if (isinf(d0)) continue;
+    const int gi = gperm[i];
+    if (isinf(D[2 * i + 2])) {
+      const int gj = gperm[i + 1];
+      const double d21 = D[2 * i + 1], d22 = D[2 * i + 3];
+      const double x1 = xp[gi], x2 = xp[gj];
+      xp[gi] = fma(d0, x1, d21 * x2);
+      xp[gj] = fma(d21, x1, d22 * x2);
+    } else {
+      xp[gi] *= d0;
+    }
+  }
+}
+
+// =================================================================================================
 // multi-GPU exchange helpers: pack / unpack the cut roots' blocks, merge / mask solution vectors
 // =================================================================================================
 struct Segment {
@@ -2454,8 +2895,8 @@ __global__ void k_solve_diag_owned(int n, const double* __restrict__ D, const in
     const int gj = gperm[i + 1];
     const double d21 = D[2 * int64_t(i) + 1], d22 = D[2 * int64_t(i) + 3];
     const double x1 = xp[gi], x2 = xp[gj];
-    xp[gi] = d0 * x1 + d21 * x2;
-    xp[gj] = d21 * x1 + d22 * x2;
+    xp[gi] = fma(d0, x1, d21 * x2);
+    xp[gj] = fma(d21, x1, d22 * x2);
   } else {
     xp[gi] *= d0;
   }
@@ -2487,7 +2928,8 @@ void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.tftasks, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.posowner, F.tppflag, F.tpplist};
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.posowner, F.tppflag, F.tpplist,
+                  F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   F = DeviceFactor();
@@ -2618,7 +3060,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       const int s = lvl_nodes[i];
       if (!wg(s))
         tft.push_back(TinyFrontTask{S.ncol(s), S.nrow(s), S.ldl[s], S.sptr[s], S.loff[s], S.coff[s], nd[s].iblk,
-                                    (S.sparent[s] < nn) ? 1 : 0, s, 0});
+                                    (S.sparent[s] < nn) ? 1 : 0, s, 0, 0, 0});
     }
     lp.tf_cnt = int(tft.size()) - lp.tf_begin;
     // extend-add: one pull task per PCOLS columns of every parent, children in clist order
@@ -2703,9 +3145,225 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     build_plan(F.planB, [&](int s) { return S.owner[s] < 0; }, all);
   }
 
+  // ---- wave tier of the LDL^T solves: stages of small subtrees, one wave each ------------------------------
+  F.wave = false;
+  if (!F.sharded && nn > 0 && !getenv("GSLS_NO_WAVE")) {
+    std::vector<char> waveT(nn);          // the front and everything below it has at most 64 rows
+    int nT = 0;
+    for (int s = 0; s < nn; ++s) waveT[s] = (S.nrow(s) <= 64);
+    for (int s = 0; s < nn; ++s) {        // supernodes are numbered in postorder: children first
+      const int p2 = S.sparent[s];
+      if (p2 < nn && !waveT[s]) waveT[p2] = 0;
+    }
+    for (int s = 0; s < nn; ++s) nT += waveT[s];
+    if (nT > 0) {
+      const int gmax = getenv("GSLS_GMAX") ? std::max(1, atoi(getenv("GSLS_GMAX"))) : 8;
+      // groups: walk the tree bottom-up; a front joins the open subtrees of its children unless that would make the
+      // group too big or too deep -- then the children's subtrees are closed (each becomes a group)
+      std::vector<int> open(nn, 0), hgt(nn, 0);
+      std::vector<char> closed(nn, 0);
+      for (int s = 0; s < nn; ++s) {
+        if (!waveT[s]) {
+          for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci)
+            if (waveT[S.clist[ci]]) closed[S.clist[ci]] = 1;
+          continue;
+        }
+        int sz = 1, h = 1;
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
+          const int c = S.clist[ci];
+          if (closed[c]) continue;
+          sz += open[c];
+          h = std::max(h, hgt[c] + 1);
+        }
+        if (sz > gmax || h > WSLOT) {
+          for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) closed[S.clist[ci]] = 1;
+          sz = 1;
+          h = 1;
+        }
+        open[s] = sz;
+        hgt[s] = h;
+        if (S.sparent[s] >= nn) closed[s] = 1;
+      }
+      // group root, depth inside the group (parents first), stage of every group (children first)
+      std::vector<int> groot(nn, -1), gdepth(nn, 0), gstage(nn, 0);
+      for (int s = nn - 1; s >= 0; --s) {
+        if (!waveT[s]) continue;
+        if (closed[s]) {
+          groot[s] = s;
+          gdepth[s] = 0;
+        } else {
+          groot[s] = groot[S.sparent[s]];
+          gdepth[s] = gdepth[S.sparent[s]] + 1;
+        }
+      }
+      int nstage = 0;
+      for (int s = 0; s < nn; ++s) {
+        if (!waveT[s] || !closed[s]) continue;
+        nstage = std::max(nstage, gstage[s] + 1);
+        const int p2 = S.sparent[s];
+        if (p2 < nn && waveT[p2]) gstage[groot[p2]] = std::max(gstage[groot[p2]], gstage[s] + 1);
+      }
+      // members of every group in postorder
+      std::vector<int> gcount(nn, 0);
+      for (int s = 0; s < nn; ++s)
+        if (waveT[s]) gcount[groot[s]]++;
+      struct GInfo { int root, stage, cnt, wide; };
+      std::vector<GInfo> gi;
+      {
+        std::vector<char> gwide(nn, 0);
+        for (int s = 0; s < nn; ++s)
+          if (waveT[s]) {
+            bool pull = false;
+            for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) pull |= bool(closed[S.clist[ci]]);
+            const bool orphan = closed[s] && S.sparent[s] < nn && !waveT[S.sparent[s]];   // its parent is outside the tier
+            if (S.ncol(s) > 32 || S.nrow(s) > 40 || pull || orphan) gwide[groot[s]] = 1;
+          }
+        for (int s = 0; s < nn; ++s)
+          if (waveT[s] && closed[s]) gi.push_back(GInfo{s, gstage[s], gcount[s], gwide[s]});
+      }
+      // launch order: by stage, narrow groups (every front <= 32 columns and <= 40 rows, no children in earlier stages,
+      // the root's parent inside the tier: what the kernels that load one front ahead handle) before wide ones, long
+      // groups first
+      std::stable_sort(gi.begin(), gi.end(), [](const GInfo& a, const GInfo& b) {
+        if (a.stage != b.stage) return a.stage < b.stage;
+        if (a.wide != b.wide) return a.wide < b.wide;
+        return a.cnt > b.cnt;
+      });
+      // A wave walks a RUN of groups one after the other (WGroup = the run's task range): what a wave pays before
+      // its first front's data arrives -- three dependent round trips -- is paid once per run instead of once per
+      // subtree, and the look-ahead carries across the subtree boundaries.  Runs of one (stage, narrow/wide) class
+      // are filled to about `wtarget` fronts: enough runs to fill the chip once, no more.
+      std::vector<int64_t> gtbeg(nn, 0);      // first task of the group rooted at node
+      std::vector<WGroup> wg;
+      F.wstage_begin.assign(nstage, 0);
+      F.wstage_cnt.assign(nstage, 0);
+      F.wstage_narrow.assign(nstage, 0);
+      {
+        std::vector<int64_t> stage_tasks(nstage, 0);
+        for (const GInfo& g : gi) stage_tasks[g.stage] += g.cnt;
+        const int wslots = getenv("GSLS_WSLOTS") ? std::max(1, atoi(getenv("GSLS_WSLOTS"))) : 4096;
+        int64_t tb = 0;
+        int cur_stage = -1, cur_wide = -1, cur_cnt = 0, target = 1;
+        for (size_t g = 0; g < gi.size(); ++g) {
+          gtbeg[gi[g].root] = tb;
+          const bool fresh = gi[g].stage != cur_stage || gi[g].wide != cur_wide || cur_cnt >= target;
+          if (fresh) {
+            if (gi[g].stage != cur_stage) F.wstage_begin[gi[g].stage] = int(wg.size());
+            cur_stage = gi[g].stage;
+            cur_wide = gi[g].wide;
+            target = getenv("GSLS_WTARGET") ? std::max(1, atoi(getenv("GSLS_WTARGET")))
+                                            : int(std::max<int64_t>(1, (stage_tasks[cur_stage] + wslots - 1) / wslots));
+            wg.push_back(WGroup{int32_t(tb), 0});
+            cur_cnt = 0;
+            F.wstage_cnt[cur_stage]++;
+            if (!cur_wide) F.wstage_narrow[cur_stage]++;
+          }
+          wg.back().tcnt += gi[g].cnt;
+          cur_cnt += gi[g].cnt;
+          tb += gi[g].cnt;
+        }
+      }
+      std::vector<WTask> wt(nT);
+      std::vector<WPack> wp(nT);
+      std::vector<int32_t> gptr(1, 0);
+      std::vector<int64_t> gsrc;
+      {
+        std::vector<int64_t> fill(gtbeg);
+        for (int s = 0; s < nn; ++s) {        // ascending node number = postorder inside every group
+          if (!waveT[s]) continue;
+          const int64_t ti = fill[groot[s]]++;
+          WTask& t = wt[ti];
+          t.m = S.nrow(s);
+          t.n = S.ncol(s);
+          t.sptr = S.sptr[s];
+          t.flags = closed[s] ? ((S.sparent[s] < nn && waveT[S.sparent[s]]) ? WT_ZVEC : 0) : WT_PUSH;
+          t.lfoff = t.lboff = 0;
+          t.roff = S.rptr[s];
+          t.moff = S.cmapptr[s];
+          t.goff = 0;
+          t.myslot = gdepth[s];
+          t.pslot = closed[s] ? 0 : gdepth[S.sparent[s]];
+          for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) t.flags |= closed[S.clist[ci]] ? WT_PULL : WT_INT;
+          wp[ti] = WPack{S.loff[s], s, 0};
+        }
+      }
+      // images and gather lists in launch order
+      int64_t of = 0, ob = 0;
+      std::vector<int64_t> nlf(nn, -1), nlb(nn, -1);
+      for (int64_t ti = 0; ti < nT; ++ti) {
+        WTask& t = wt[ti];
+        const int s = wp[ti].node, pm = t.m;
+        t.lfoff = of;
+        t.lboff = ob;
+        nlf[s] = of;
+        nlb[s] = ob;
+        of += wf_size(t.m, t.n);
+        ob += wb_size(t.m, t.n);
+        if (!(t.flags & WT_PULL)) continue;
+        t.goff = int64_t(gptr.size()) - 1;
+        std::vector<std::vector<int64_t>> rows(pm);
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
+          const int c = S.clist[ci];
+          if (!closed[c]) continue;            // children inside the group arrive through LDS
+          const int ccm = S.nrow(c) - S.ncol(c);
+          for (int k = 0; k < ccm; ++k) rows[S.cmap[S.cmapptr[c] + k]].push_back(S.cmapptr[c] + k);
+        }
+        for (int r2 = 0; r2 < pm; ++r2) {
+          gsrc.insert(gsrc.end(), rows[r2].begin(), rows[r2].end());
+          gptr.push_back(int32_t(gsrc.size()));
+        }
+        gptr.push_back(int32_t(gsrc.size()));   // one spare entry: every task owns m + 1 consecutive pointers
+      }
+      for (auto& tk : tft) {
+        tk.lfoff = nlf[tk.node];
+        tk.lboff = nlb[tk.node];
+      }
+      std::vector<int32_t> nont;
+      for (int s = 0; s < nn; ++s)
+        if (!waveT[s]) nont.push_back(s);
+      F.wnont_cnt = int(nont.size());
+      F.wtask_cnt = nT;
+      F.Lf_elems = of;
+      F.Lb_elems = ob;
+      {
+        WTask* d1 = nullptr;
+        WGroup* d2 = nullptr;
+        WPack* d3 = nullptr;
+        HIPCHK(upload(d1, wt, st));
+        HIPCHK(upload(d2, wg, st));
+        HIPCHK(upload(d3, wp, st));
+        F.wtasks = d1;
+        F.wgroups = d2;
+        F.wpacks = d3;
+      }
+      HIPCHK(upload(F.wgth_ptr, gptr, st));
+      HIPCHK(upload(F.wgth_src, gsrc, st));
+      HIPCHK(upload(F.wnont, nont, st));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.Lf), std::max<int64_t>(of, 2) * sizeof(double)));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.Lb), std::max<int64_t>(ob, 2) * sizeof(double)));
+      HIPCHK(hipMemsetAsync(F.Lf, 0, std::max<int64_t>(of, 2) * sizeof(double), st));   // the diagonal slots stay 0
+      HIPCHK(hipMemsetAsync(F.Lb, 0, std::max<int64_t>(ob, 2) * sizeof(double), st));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xs), (std::max(S.n, 1) + 64) * sizeof(double)));
+      HIPCHK(hipMemsetAsync(F.xs, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gvar), (std::max(S.n, 1) + 64) * sizeof(int32_t)));
+      HIPCHK(hipMemsetAsync(F.gvar, 0, (std::max(S.n, 1) + 64) * sizeof(int32_t), st));
+      build_plan(F.planW, [&](int s) { return !waveT[s]; }, all);
+      F.wave = true;
+      if (getenv("GSLS_DEBUG")) {
+        fprintf(stderr, "[gsls] wave tier: %d of %d fronts in %zu groups, %zu runs, %d stages (runs per stage:", nT, nn, gi.size(), wg.size(), nstage);
+        for (int k = 0; k < nstage; ++k) fprintf(stderr, " %d", F.wstage_cnt[k]);
+        fprintf(stderr, "), images %.1f + %.1f MB\n", of * 8e-6, ob * 8e-6);
+      }
+    }
+  }
+
   HIPCHK(upload(F.nodes, nd, st));
   HIPCHK(upload(F.rlist, S.rlist, st));
-  HIPCHK(upload(F.cmap, S.cmap, st));
+  {
+    std::vector<int> cm2(S.cmap);           // + 64: the wave tier reads cmap[moff + lane] unmasked
+    cm2.resize(cm2.size() + 64, 0);
+    HIPCHK(upload(F.cmap, cm2, st));
+  }
   HIPCHK(upload(F.clist, S.clist, st));
   HIPCHK(upload(F.lvlnodes, S.lvlnodes, st));
   HIPCHK(upload(F.smallnodes, smalln, st));
@@ -2825,9 +3483,13 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   F.cvec_elems = S.cmapptr[nn];
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.L), std::max<int64_t>(F.L_elems, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.C), std::max<int64_t>(F.C_elems, 1) * sizeof(double)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.D), (2 * int64_t(S.n) + 4) * sizeof(double)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gperm), std::max(S.n, 1) * sizeof(int32_t)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), std::max<int64_t>(F.cvec_elems, 1) * sizeof(double)));
+  // (+ 64 elements / 132 doubles of padding: the wave tier loads [sptr + lane] and [moff + lane] unmasked)
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.D), (2 * int64_t(S.n) + 4 + 132) * sizeof(double)));
+  HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4 + 132) * sizeof(double), st));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gperm), (std::max(S.n, 1) + 64) * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(F.gperm, 0, (std::max(S.n, 1) + 64) * sizeof(int32_t), st));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), (std::max<int64_t>(F.cvec_elems, 1) + 64) * sizeof(double)));
+  HIPCHK(hipMemsetAsync(F.cvec, 0, (std::max<int64_t>(F.cvec_elems, 1) + 64) * sizeof(double), st));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), NSTAT * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.faillist), FAILCAP * sizeof(int32_t)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.fastok), std::max<int64_t>(F.nblk64, 1) * sizeof(int32_t)));
@@ -2862,7 +3524,8 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
     if (!POSDEF && lp.tf_cnt > 0)   // only in the tiny-front plan (planT)
       hipLaunchKernelGGL(k_front_tiny, dim3((lp.tf_cnt + 3) / 4), dim3(256), 0, st,
                          static_cast<const TinyFrontTask*>(F.tftasks) + lp.tf_begin, lp.tf_cnt, F.L, F.D, F.C,
-                         F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail, small, u);
+                         F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr,
+                         F.wave ? F.Lb : nullptr);
     const int nsteps = int(lp.panel_cnt.size() / 2);
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
@@ -3027,12 +3690,23 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
     HIPCHK(ensure_linv(F));
     return factor_levels<true>(S, F, F.plan, small, u, st);
   }
-  return factor_levels<false>(S, F, use_tiny ? F.planT : F.plan, small, u, st);
+  hipError_t e = factor_levels<false>(S, F, use_tiny ? F.planT : F.plan, small, u, st);
+  if (e != hipSuccess) return e;
+  if (F.wave && F.wtask_cnt > 0)   // packed images of the wave-tier fronts the workgroup kernels factorized
+    hipLaunchKernelGGL(k_wpack, dim3((F.wtask_cnt + 3) / 4), dim3(256), 0, st, static_cast<const WTask*>(F.wtasks),
+                       static_cast<const WPack*>(F.wpacks), F.wtask_cnt, use_tiny ? 1 : 0, F.tinyskip, F.L, F.Lf, F.Lb);
+  if (F.wave)
+    hipLaunchKernelGGL(k_gvar, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm, F.invp, F.gvar);
+  return hipGetLastError();
 }
 
+// wave: the wave tier (LDL^T fronts of at most 64 rows) runs beside `plan`, which then holds the other fronts only;
+// xin / xout: the caller's vector when the tier reads the right-hand side / writes the solution itself
 template <bool POSDEF>
 static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::vector<LevelPlan>& plan,
-                               int job, double* xp, hipStream_t st, hipEvent_t* ev, int diag_sel = -2) {
+                               int job, double* xp, hipStream_t st, hipEvent_t* ev, int diag_sel = -2,
+                               bool wave = false, const double* xin = nullptr, double* xout = nullptr,
+                               const double* scale = nullptr) {
   const bool do_fwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
   const bool do_diag = !POSDEF && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_DIAG ||
                                    job == GSLS_SOLVE_JOB_DIAG_BWD);
@@ -3040,7 +3714,37 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
                        job == GSLS_SOLVE_JOB_DIAG_BWD);
   const BigTrsv* btr = static_cast<const BigTrsv*>(F.bigtrsv);
   const BigGemv* bgm = static_cast<const BigGemv*>(F.biggemv);
+  const WGroup* wgr = static_cast<const WGroup*>(F.wgroups);
+  const WTask* wtk = static_cast<const WTask*>(F.wtasks);
+  const bool fuse_d = wave && do_fwd && do_diag;     // the tier applies D^-1 at the end of its forward step
+  // job ALL: the tier's forward result stays by pivot slot (F.xs) for its own backward kernels
+  double* slotv = (wave && do_fwd && do_bwd) ? F.xs : nullptr;
+  auto wave_fwd = [&](int g0, int cnt, bool narrow) {
+    if (cnt <= 0) return;
+#define GSLS_WFWD(D_, N_)                                                                                          \
+  hipLaunchKernelGGL((k_wsolve_fwd<D_, N_>), dim3((cnt + 3) / 4), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
+                     F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, F.cvec)
+    if (fuse_d) { if (narrow) GSLS_WFWD(true, true); else GSLS_WFWD(true, false); }
+    else { if (narrow) GSLS_WFWD(false, true); else GSLS_WFWD(false, false); }
+#undef GSLS_WFWD
+  };
+  auto wave_bwd = [&](int g0, int cnt, bool narrow) {
+    if (cnt <= 0) return;
+    if (narrow)
+      hipLaunchKernelGGL(k_wsolve_bwd<true>, dim3((cnt + 3) / 4), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, F.cvec);
+    else
+      hipLaunchKernelGGL(k_wsolve_bwd<false>, dim3((cnt + 3) / 4), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, F.cvec);
+  };
   if (ev) HIPCHK(hipEventRecord(ev[0], st));
+  const bool ahead = slotv != nullptr && scale == nullptr;  // the look-ahead kernels: job ALL, no user scaling
+  if (do_fwd && wave)
+    for (size_t k = 0; k < F.wstage_cnt.size(); ++k) {      // stages of small subtrees, bottom-up
+      const int nar = ahead ? F.wstage_narrow[k] : 0;
+      wave_fwd(F.wstage_begin[k], nar, true);
+      wave_fwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false);
+    }
   if (do_fwd)
     for (int l = 0; l < S.nlevels; ++l) {
       const LevelPlan& lp = plan[l];
@@ -3080,7 +3784,10 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
       }
     }
   if (ev) HIPCHK(hipEventRecord(ev[1], st));
-  if (do_diag) {
+  if (fuse_d) {
+    if (F.wnont_cnt > 0)
+      hipLaunchKernelGGL(k_solve_diag_nodes, dim3(F.wnont_cnt), dim3(256), 0, st, F.nodes, F.wnont, F.D, F.gperm, xp);
+  } else if (do_diag) {
     if (diag_sel == -2)
       hipLaunchKernelGGL(k_solve_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm, xp);
     else
@@ -3125,6 +3832,12 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
         }
       }
     }
+  if (do_bwd && wave)
+    for (int k = int(F.wstage_cnt.size()) - 1; k >= 0; --k) {
+      const int nar = ahead ? F.wstage_narrow[k] : 0;
+      wave_bwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false);
+      wave_bwd(F.wstage_begin[k], nar, true);
+    }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));
   return hipGetLastError();
 }
@@ -3132,10 +3845,13 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev) {
   if (F.nrhs_cap < 1) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), std::max(S.n, 1) * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(F.xp, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
     F.nrhs_cap = 1;
   }
   const int blocks = (S.n + 255) / 256;
+  const bool wave = F.wave && !posdef;
+  const bool has_bwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD || job == GSLS_SOLVE_JOB_DIAG_BWD);
   // which side of the permutation/scaling each job touches (fkeep.F90:229-318)
   for (int r = 0; r < nrhs; ++r) {
     double* x = d_x + int64_t(r) * ldx;
@@ -3143,13 +3859,20 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
     const bool scale_in = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
     const bool scale_out = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD ||
                                        job == GSLS_SOLVE_JOB_DIAG_BWD);
+    // the wave tier writes the solution into the caller's vector itself; the separate output permutation is only
+    // needed for the fronts it does not cover and for the jobs without a backward sweep
+    const bool fuse_out = wave && has_bwd;
     hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
-                       scale_in ? d_scale : nullptr, F.xp);
-    hipError_t e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, (r == 0) ? ev : nullptr)
-                          : solve_sweeps<false>(S, F, F.plan, job, F.xp, st, (r == 0) ? ev : nullptr);
+                         scale_in ? d_scale : nullptr, F.xp);
+    hipEvent_t* evr = (r == 0) ? ev : nullptr;
+    hipError_t e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, evr)
+                   : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, nullptr,
+                                                fuse_out ? x : nullptr, scale_out ? d_scale : nullptr)
+                          : solve_sweeps<false>(S, F, F.plan, job, F.xp, st, evr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.xp,
-                       scale_out ? d_scale : nullptr, x);
+    if (!fuse_out || F.wnont_cnt > 0)
+      hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.xp,
+                         scale_out ? d_scale : nullptr, x);
   }
   return hipGetLastError();
 }

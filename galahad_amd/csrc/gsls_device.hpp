@@ -102,6 +102,7 @@ struct DeviceFactor {
   int64_t nscatter = 0;
   std::vector<LevelPlan> plan;    // every front (single device)
   std::vector<LevelPlan> planT;   // LDL^T refactorizations: tiny fronts go to k_front_tiny, the rest as in `plan`
+  std::vector<LevelPlan> planW;   // wave tier active: the fronts it does not cover (more than 64 rows)
   std::vector<LevelPlan> planA;   // multi-GPU: the subtrees this rank owns
   std::vector<LevelPlan> planB;   // multi-GPU: the top part (run by rank 0 after the exchange)
   bool sharded = false;
@@ -113,6 +114,23 @@ struct DeviceFactor {
   void* segV = nullptr;
   int nseg = 0;
   int32_t* posowner = nullptr;    // pivot position -> owner rank of its front (-1 top)
+  // wave tier of the LDL^T solves (fronts of at most 64 rows; gsls_device.hip, "WAVE TIER")
+  bool wave = false;
+  void* wtasks = nullptr;         // WTask per covered front, group by group, postorder inside a group
+  void* wgroups = nullptr;        // WGroup records in launch order (by stage)
+  void* wpacks = nullptr;         // WPack per task (pack kernel)
+  int wtask_cnt = 0;
+  std::vector<int> wstage_begin, wstage_cnt, wstage_narrow;   // per stage: group range, and how many of its first
+                                                              // groups hold fronts of at most 32 columns only
+  int32_t* wgth_ptr = nullptr;    // gather lists of the covered fronts (rows -> children's contribution entries)
+  int64_t* wgth_src = nullptr;
+  int32_t* wnont = nullptr;       // fronts the tier does not cover (for the D solve)
+  int wnont_cnt = 0;
+  double* Lf = nullptr;           // packed forward / backward images of the covered fronts
+  double* Lb = nullptr;
+  int64_t Lf_elems = 0, Lb_elems = 0;
+  double* xs = nullptr;           // forward result of the covered fronts by pivot slot (job ALL)
+  int32_t* gvar = nullptr;        // pivot slot -> variable, refreshed by every factorization
   // numeric
   double* L = nullptr;
   double* Linv = nullptr;        // Cholesky only: L11^-T of every 64-column block, nblk64 x 64 x 64
