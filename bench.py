@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--ordering", choices=["free", "natural"], default="free",
                     help="free: the backend's own ordering (perf run); natural: identity PERM (parity run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-facade", action="store_true", help="skip the SLS / SBLS facade timings (extra block `facade`)")
     ap.add_argument("--nemin", type=int, default=0, help="supernode amalgamation (0: backend default)")
     ap.add_argument("--shard", choices=["replicas", "tree"], default="replicas",
                     help="N>1: replicas = one independent system per GPU (weak scaling, the default); tree = "
@@ -114,6 +115,38 @@ def cpu_baseline(prob, posdef, perm, nemin):
             "flops_elimination": r["flops_elimination"], "entries_in_factors": r["entries_in_factors"],
             "delayed_pivots": r["delayed"], "negative_eigenvalues": r["negative_eigenvalues"],
             "max_err": float(np.abs(r["x"] - xs).max())}
+
+
+def facade_timings(prob, a, nemin):
+    """What a GALAHAD caller gets: the REAL SLS / SBLS facades (reference Fortran, built by oracle/build_ref.sh with the
+    gsls arms of INTEGRATION.md) over this backend on the same system -- host arrays in, host x out, the facade's own
+    clocks (inform%time%clock_factorize / clock_solve semantics: median over repeats, analyse excluded)."""
+    from oracle import refio
+    if not refio.dropin_available():
+        return None
+    n, row, col, val, rhs, xs = prob
+    out = {}
+    try:
+        r = refio.run(n, row, col, val, rhs, solver="gsls", pivot_control=1, nemin=nemin, repeat=7, max_refine=0)
+        r1 = refio.run(n, row, col, val, rhs, solver="gsls", pivot_control=1, nemin=nemin, repeat=7, max_refine=1)
+        out["sls"] = {"factorize_ms": r["t_factorize_median"] * 1e3, "solve_ms": r["t_solve_median"] * 1e3,
+                      "solve_with_one_refinement_ms": r1["t_solve_median"] * 1e3,
+                      "status": [r["status_analyse"], r["status_factorize"], r["status_solve"]],
+                      "max_err": float(np.abs(r["x"] - xs).max())}
+        if refio.sbls_available(dropin=True):
+            i = np.arange(a.n)
+            H = (np.concatenate([i, i[1:]]) + 1, np.concatenate([i, i[:-1]]) + 1, val[: 2 * a.n - 1])
+            A = (np.concatenate([np.arange(a.m), np.arange(a.m)]) + 1,
+                 np.concatenate([np.arange(a.m), a.m + np.arange(a.m)]) + 1, np.ones(2 * a.m))
+            Cm = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
+            rs = refio.run_sbls(a.n, a.m, H, A, Cm, rhs, solver="gsls", factorization=2, repeat=7, itref_max=1)
+            out["sbls"] = {"form_and_factorize_ms": rs["t_factorize_median"] * 1e3, "solve_ms": rs["t_solve_median"] * 1e3,
+                           "status": [rs["status_factorize"], rs["status_solve"]],
+                           "max_err": float(np.abs(rs["sol"] - xs).max()),
+                           "note": "SBLS_solve refines with its own host loops over K (src/sbls/sbls.f90:5343-5372)"}
+    except Exception as e:      # the facade run is a report, not the metric
+        out["error"] = repr(e)[:200]
+    return out
 
 
 def main():
@@ -298,6 +331,10 @@ def main():
         }
         if drift is not None:
             out["drift"] = drift
+        if world == 1 and kkt and not a.no_facade:
+            fc = facade_timings(prob, a, c.node_amalgamation)
+            if fc:
+                out["facade"] = fc
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(prob, posdef, order if (kkt or a.ordering == "natural") else np.arange(1, n + 1),
                               c.node_amalgamation)

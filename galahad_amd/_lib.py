@@ -45,6 +45,15 @@ SIGNATURES = {
                               C.POINTER(Inform)]),
     "gsls_factor_dev": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),
                                   C.POINTER(Inform)]),
+    "gsls_set_coo": (C.c_int, [C.c_void_p, i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsls_factor_coo": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),
+                                  C.POINTER(Inform)]),
+    "gsls_factor_coo_dev": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),
+                                      C.POINTER(Inform)]),
+    "gsls_residual": (C.c_int, [C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32,
+                                C.POINTER(Inform)]),
+    "gsls_solve_ir": (C.c_int, [C.c_void_p, C.c_void_p, i32, f64, f64, C.POINTER(i32), C.POINTER(Options),
+                                C.POINTER(Inform)]),
     "gsls_solve": (C.c_int, [C.c_void_p, i32, i32, C.c_void_p, i32, C.POINTER(Options),
                              C.POINTER(Inform)]),
     "gsls_solve_dev": (C.c_int, [C.c_void_p, i32, i32, C.c_void_p, i32, C.POINTER(Options),

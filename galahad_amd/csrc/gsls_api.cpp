@@ -46,6 +46,9 @@ struct Handle {
   std::vector<int32_t> partner;   // per variable: the variable it was paired with by the pre-ordering, or -1
   bool tpp_unflagged = false;     // the flags were dropped once after learning; if failures return they stay
   bool tpp_dirty = false;
+  bool have_coo = false;          // gsls_set_coo has been called for the analysed pattern
+  bool coo_uploaded = false;      // ... and its structure is on the device
+  std::vector<int32_t> coo_row, coo_col, coo_map;
   int shard_repairs = 0;          // repair rounds of the sharded path (plan_repair's pass counter)         // the device-side front flags no longer match tppvar / the current tree
   int nemin = 32;
   double kt_fwd = 0, kt_diag = 0, kt_bwd = 0;
@@ -262,6 +265,7 @@ int gsls_destroy(void** handle) {
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     dev_free(h->F);
+    dev_free_coo(h->F);
     for (auto& ev : h->ev)
       if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -285,6 +289,7 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
   }
   const double t0 = now();
   h->analysed = h->factored = h->dev_ready = false;
+  h->have_coo = h->coo_uploaded = false;
   h->learned = 0;
   h->tiny_ready = false;
   h->tiny_strikes = 0;
@@ -367,7 +372,10 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
   std::vector<double> hv;
   if (on_device) {
     hv.resize(nzv);
-    hipError_t e = hipMemcpy(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost);
+    // on the handle's stream: the values may just have been produced there (gsls_factor_coo maps them on the device)
+    hipError_t e = h->stream ? hipMemcpyAsync(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost, h->stream)
+                             : hipMemcpy(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && h->stream) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     val = hv.data();
   }
@@ -747,6 +755,216 @@ int gsls_factor_dev(void* handle, int32_t posdef, const double* d_val, const dou
   return factor_common(static_cast<Handle*>(handle), posdef, d_val, d_scale, true, options, inform);
 }
 
+// ---- the caller's own matrix on the device (include/gsls.h; SLS_factorize's scatter sls.f90:4113-4150, the
+// residual of SLS_solve_ir sls.f90:4826-4934) ------------------------------------------------------------------
+int gsls_set_coo(void* handle, int64_t ne, const int32_t* row, const int32_t* col, const int32_t* map) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || ne < 0 || (ne > 0 && !map)) return GSLS_ERROR_CALL_SEQUENCE;
+  // kept on the host until the first factorization needs it: analyse must work without a device
+  try {
+    h->coo_map.assign(map, map + ne);
+    if (row && col) {
+      h->coo_row.assign(row, row + ne);
+      h->coo_col.assign(col, col + ne);
+    } else {
+      h->coo_row.clear();
+      h->coo_col.clear();
+    }
+  } catch (const std::bad_alloc&) {
+    return GSLS_ERROR_ALLOCATION;
+  }
+  h->have_coo = true;
+  h->coo_uploaded = false;
+  return GSLS_SUCCESS;
+}
+
+// upload the caller's matrix structure if that has not happened yet
+static hipError_t sync_coo(Handle* h) {
+  if (h->coo_uploaded || h->S.n == 0) return hipSuccess;
+  hipError_t e = ensure_device(h, nullptr);
+  if (e != hipSuccess) return e;
+  const int64_t ne = int64_t(h->coo_map.size());
+  const bool rc = !h->coo_row.empty() || ne == 0;
+  e = dev_set_coo(h->F, h->S.n, h->ptr[h->S.n] - 1, ne, rc ? h->coo_row.data() : nullptr,
+                  rc ? h->coo_col.data() : nullptr, h->coo_map.data(), h->stream);
+  if (e == hipSuccess) h->coo_uploaded = true;
+  return e;
+}
+
+static int factor_coo_common(Handle* h, int posdef, const double* val, const double* scale, bool on_device,
+                             const gsls_options* options, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  if (!h || !h->analysed || !h->have_coo) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  if (h->S.n == 0) return factor_common(h, posdef, val, scale, on_device, options, inform);
+  if (!val) {
+    *inform = h->last;
+    return inform->flag = GSLS_ERROR_VAL;
+  }
+  hipError_t e = ensure_device(h, options);
+  if (e != hipSuccess) {
+    *inform = h->last;
+    return fail_hip(h, inform, e);
+  }
+  DeviceGuard g(h->device);
+  try {
+    e = sync_coo(h);
+  } catch (const std::bad_alloc&) {
+    *inform = h->last;
+    return inform->flag = GSLS_ERROR_ALLOCATION;
+  }
+  if (e != hipSuccess) {
+    *inform = h->last;
+    return fail_hip(h, inform, e);
+  }
+  if (on_device) e = hipMemcpyAsync(h->F.coo_val, val, h->F.coo_ne * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+  else e = hipMemcpyAsync(h->F.coo_val, val, h->F.coo_ne * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = dev_map_values(h->F, h->F.coo_val, h->stream);
+  if (e != hipSuccess) {
+    *inform = h->last;
+    return fail_hip(h, inform, e);
+  }
+  const double* d_scale = scale;
+  if (scale && !on_device) {      // the scale vector follows the values onto the device
+    if (!h->F.scale) {
+      e = hipMalloc(reinterpret_cast<void**>(&h->F.scale), h->S.n * sizeof(double));
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+    }
+    e = hipMemcpyAsync(h->F.scale, scale, h->S.n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    d_scale = h->F.scale;
+  }
+  return factor_common(h, posdef, h->F.valcsc, d_scale, true, options, inform);
+}
+
+int gsls_factor_coo(void* handle, int32_t posdef, const double* val, const double* scale,
+                    const gsls_options* options, gsls_inform* inform) {
+  return factor_coo_common(static_cast<Handle*>(handle), posdef, val, scale, false, options, inform);
+}
+
+int gsls_factor_coo_dev(void* handle, int32_t posdef, const double* d_val, const double* d_scale,
+                        const gsls_options* options, gsls_inform* inform) {
+  return factor_coo_common(static_cast<Handle*>(handle), posdef, d_val, d_scale, true, options, inform);
+}
+
+int gsls_residual(void* handle, int32_t nrhs, const double* x, int32_t ldx, const double* b, int32_t ldb,
+                  double* r, int32_t ldr, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->have_coo || !h->coo_uploaded || (h->S.n > 0 && !h->F.rs_ptr)) {
+    std::memset(inform, 0, sizeof(*inform));      // (needs gsls_set_coo with row / col and a gsls_factor_coo)
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  const int n = h->S.n;
+  const double t0r = now();
+  if (nrhs < 1 || ldx < n || ldb < n || ldr < n || (n > 0 && (!x || !b || !r))) return inform->flag = GSLS_ERROR_X_SIZE;
+  if (n == 0) return GSLS_SUCCESS;
+  DeviceGuard g(h->device);
+  DeviceFactor& F = h->F;
+  const int64_t need = 3 * int64_t(n) * nrhs;
+  hipError_t e;
+  if (F.rbuf_cap < need) {
+    if (F.rbuf) (void)hipFree(F.rbuf);
+    F.rbuf = nullptr;
+    F.rbuf_cap = 0;
+    e = hipMalloc(reinterpret_cast<void**>(&F.rbuf), need * sizeof(double));
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    F.rbuf_cap = need;
+  }
+  double *dx = F.rbuf, *db = F.rbuf + int64_t(n) * nrhs, *dr = F.rbuf + 2 * int64_t(n) * nrhs;
+  for (int k = 0; k < nrhs; ++k) {
+    e = hipMemcpyAsync(dx + int64_t(k) * n, x + int64_t(k) * ldx, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    e = hipMemcpyAsync(db + int64_t(k) * n, b + int64_t(k) * ldb, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+  }
+  e = dev_residual(F, n, nrhs, dx, n, db, n, dr, n, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  for (int k = 0; k < nrhs; ++k) {
+    e = hipMemcpyAsync(r + int64_t(k) * ldr, dr + int64_t(k) * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+  }
+  e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] residual: %.3f ms\n", (now() - t0r) * 1e3);
+  return inform->flag;
+}
+
+static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool on_device,
+                        gsls_inform* inform);
+
+// SLS_solve_ir (sls.f90:4770-4949) with every vector resident in HBM: b in, x out, nothing else crosses the bus
+int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double residual_absolute,
+                  double residual_relative, int32_t* iterations, const gsls_options*, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->factored || !h->have_coo || !h->coo_uploaded || (h->S.n > 0 && !h->F.rs_ptr)) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  if (iterations) *iterations = 0;
+  const int n = h->S.n;
+  if (n == 0) return GSLS_SUCCESS;
+  if (!x) return inform->flag = GSLS_ERROR_X_SIZE;
+  DeviceGuard g(h->device);
+  DeviceFactor& F = h->F;
+  const int64_t need = 3 * int64_t(n) + 2;
+  hipError_t e;
+  if (F.rbuf_cap < need) {
+    if (F.rbuf) (void)hipFree(F.rbuf);
+    F.rbuf = nullptr;
+    F.rbuf_cap = 0;
+    e = hipMalloc(reinterpret_cast<void**>(&F.rbuf), need * sizeof(double));
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    F.rbuf_cap = need;
+  }
+  double *dX = F.rbuf, *dB = F.rbuf + n, *dR = F.rbuf + 2 * int64_t(n);
+  unsigned long long* dmax = reinterpret_cast<unsigned long long*>(F.rbuf + 3 * int64_t(n));
+  auto max_abs = [&](const double* v, double& out) -> hipError_t {
+    hipError_t e2 = dev_max_abs(n, v, dmax, h->stream);
+    if (e2 != hipSuccess) return e2;
+    unsigned long long bits = 0;
+    e2 = hipMemcpyAsync(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, h->stream);
+    if (e2 != hipSuccess) return e2;
+    e2 = hipStreamSynchronize(h->stream);
+    std::memcpy(&out, &bits, sizeof(out));
+    return e2;
+  };
+  e = hipMemcpyAsync(dB, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dR, dB, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(dX, 0, n * sizeof(double), h->stream);
+  double residual_zero = 0.0, residual = 0.0;
+  if (e == hipSuccess) e = max_abs(dB, residual_zero);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  for (int iter = 0; iter <= std::max(max_refinements, 0); ++iter) {
+    if (iterations) *iterations = iter;
+    gsls_inform si;
+    const int f = solve_common(h, GSLS_SOLVE_JOB_ALL, 1, dR, n, true, &si);
+    if (f < 0) {
+      *inform = si;
+      return f;
+    }
+    e = dev_vec_add(n, dX, dR, h->stream);
+    if (e == hipSuccess && iter < max_refinements) e = dev_residual(F, n, 1, dX, n, dB, n, dR, n, h->stream);
+    if (e == hipSuccess) e = max_abs(dR, residual);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    if (residual < std::max(residual_absolute, residual_relative * residual_zero)) break;
+  }
+  e = hipMemcpyAsync(x, dX, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  return inform->flag;
+}
+
 static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool on_device,
                         gsls_inform* inform) {
   gsls_inform local;
@@ -770,10 +988,14 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
   double* d_x = x;
   const int64_t xelems = int64_t(ldx) * (nrhs - 1) + S.n;
   if (!on_device) {
-    if (F.xhost) (void)hipFree(F.xhost);
-    F.xhost = nullptr;
-    e = hipMalloc(reinterpret_cast<void**>(&F.xhost), xelems * sizeof(double));
-    if (e != hipSuccess) return fail_hip(h, inform, e);
+    if (F.xhost_cap < xelems) {        // kept between calls: an allocation per solve costs more than the solve
+      if (F.xhost) (void)hipFree(F.xhost);
+      F.xhost = nullptr;
+      F.xhost_cap = 0;
+      e = hipMalloc(reinterpret_cast<void**>(&F.xhost), xelems * sizeof(double));
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      F.xhost_cap = xelems;
+    }
     e = hipMemcpyAsync(F.xhost, x, xelems * sizeof(double), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     d_x = F.xhost;
@@ -791,6 +1013,7 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
   if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->kt_diag = ms * 1e-3;
   if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->kt_bwd = ms * 1e-3;
   inform->time_solve = now() - t0;
+  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] solve job %d nrhs %d: %.3f ms\n", job, nrhs, inform->time_solve * 1e3);
   inform->solve_bytes = 2 * 8 * S.num_factor + (h->posdef ? 0 : 16 * int64_t(S.n)) + 32 * int64_t(S.n);
   return inform->flag;
 }

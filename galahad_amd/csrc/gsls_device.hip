@@ -2932,7 +2932,14 @@ void dev_free(DeviceFactor& F) {
                   F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  F = DeviceFactor();
+  // the caller's matrix (gsls_set_coo) depends on the pattern only, not on the elimination order: it survives
+  // the re-analyses of order repair and learning; dev_free_coo releases it
+  DeviceFactor keep;
+  keep.coo_ne = F.coo_ne; keep.coo_nz = F.coo_nz; keep.nscatter_coo = F.nscatter_coo;
+  keep.mv_ptr = F.mv_ptr; keep.mv_src = F.mv_src; keep.rs_ptr = F.rs_ptr; keep.rs_col = F.rs_col;
+  keep.rs_src = F.rs_src; keep.coo_val = F.coo_val; keep.valcsc = F.valcsc; keep.rbuf = F.rbuf;
+  keep.rbuf_cap = F.rbuf_cap;
+  F = keep;
 }
 
 static hipError_t allow_big_lds() {
@@ -3635,6 +3642,129 @@ hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std:
   }
   HIPCHK(hipMemcpyAsync(F.tinyskip, skip.data(), skip.size(), hipMemcpyHostToDevice, st));
   return hipStreamSynchronize(st);
+}
+
+// =================================================================================================
+// the caller's own matrix on the device (gsls_set_coo / gsls_factor_coo / gsls_residual)
+// =================================================================================================
+// VAL(k) = sum of the caller's entries mapped to position k, in entry order (sls.f90:4113-4121)
+__global__ void k_map_values(int64_t nz, const int64_t* __restrict__ ptr, const int32_t* __restrict__ src,
+                             const double* __restrict__ vin, double* __restrict__ vout) {
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= nz) return;
+  double v = 0.0;
+  for (int64_t e = ptr[k]; e < ptr[k + 1]; ++e) v += vin[src[e]];
+  vout[k] = v;
+}
+// r_i = b_i - sum_e val[src[e]] x[col[e]] over row i of the full symmetric matrix, entries in storage order
+__global__ void k_coo_residual(int n, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                               const int32_t* __restrict__ src, const double* __restrict__ val,
+                               const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = b[i];
+  for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e) v -= val[src[e]] * x[col[e]];
+  r[i] = v;
+}
+
+__global__ void k_vec_add(int n, double* __restrict__ x, const double* __restrict__ r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += r[i];
+}
+// max |v_i|: non-negative doubles order like their bit patterns, so an integer atomicMax is exact and deterministic
+__global__ void k_max_abs(int n, const double* __restrict__ v, unsigned long long* __restrict__ out) {
+  double m = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmax(m, fabs(v[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+hipError_t dev_vec_add(int n, double* d_x, const double* d_r, hipStream_t st) {
+  hipLaunchKernelGGL(k_vec_add, dim3((n + 255) / 256), dim3(256), 0, st, n, d_x, d_r);
+  return hipGetLastError();
+}
+hipError_t dev_max_abs(int n, const double* d_v, unsigned long long* d_out, hipStream_t st) {
+  HIPCHK(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_max_abs, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, st, n, d_v, d_out);
+  return hipGetLastError();
+}
+
+void dev_free_coo(DeviceFactor& F) {
+  void* ptrs[] = {F.mv_ptr, F.mv_src, F.rs_ptr, F.rs_col, F.rs_src, F.coo_val, F.valcsc, F.rbuf};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  F.mv_ptr = F.rs_ptr = nullptr;
+  F.mv_src = F.rs_col = F.rs_src = nullptr;
+  F.coo_val = F.valcsc = F.rbuf = nullptr;
+  F.coo_ne = F.coo_nz = F.rbuf_cap = 0;
+}
+
+hipError_t dev_set_coo(DeviceFactor& F, int n, int64_t nzcsc, int64_t ne, const int32_t* row, const int32_t* col,
+                       const int32_t* map, hipStream_t st) {
+  dev_free_coo(F);
+  // by destination: the caller's entries of every CSC position, in entry order
+  std::vector<int64_t> mptr(nzcsc + 1, 0);
+  for (int64_t l = 0; l < ne; ++l) {
+    const int64_t k = map[l] < 0 ? -int64_t(map[l]) : map[l];
+    if (k >= 1 && k <= nzcsc) mptr[k]++;
+  }
+  for (int64_t k = 0; k < nzcsc; ++k) mptr[k + 1] += mptr[k];
+  std::vector<int32_t> msrc(mptr[nzcsc]);
+  {
+    std::vector<int64_t> fill(mptr.begin(), mptr.end() - 1);
+    for (int64_t l = 0; l < ne; ++l) {
+      const int64_t k = map[l] < 0 ? -int64_t(map[l]) : map[l];
+      if (k >= 1 && k <= nzcsc) msrc[fill[k - 1]++] = int32_t(l);
+    }
+  }
+  HIPCHK(upload(F.mv_ptr, mptr, st));
+  HIPCHK(upload(F.mv_src, msrc, st));
+  F.coo_ne = ne;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.coo_val), std::max<int64_t>(ne, 1) * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.valcsc), std::max<int64_t>(nzcsc, 1) * sizeof(double)));
+  F.nscatter_coo = nzcsc;
+  if (row && col) {
+    // the full symmetric matrix by rows (both triangles), out-of-range entries dropped (sls.f90:4901)
+    std::vector<int64_t> rptr(n + 1, 0);
+    auto ok = [&](int64_t l) { return row[l] >= 1 && row[l] <= n && col[l] >= 1 && col[l] <= n; };
+    for (int64_t l = 0; l < ne; ++l)
+      if (ok(l)) {
+        rptr[row[l]]++;
+        if (row[l] != col[l]) rptr[col[l]]++;
+      }
+    for (int i = 0; i < n; ++i) rptr[i + 1] += rptr[i];
+    std::vector<int32_t> rcol(rptr[n]), rsrc(rptr[n]);
+    std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+    for (int64_t l = 0; l < ne; ++l)
+      if (ok(l)) {
+        const int i = row[l] - 1, j = col[l] - 1;
+        rcol[fill[i]] = j;
+        rsrc[fill[i]++] = int32_t(l);
+        if (i != j) {
+          rcol[fill[j]] = i;
+          rsrc[fill[j]++] = int32_t(l);
+        }
+      }
+    HIPCHK(upload(F.rs_ptr, rptr, st));
+    HIPCHK(upload(F.rs_col, rcol, st));
+    HIPCHK(upload(F.rs_src, rsrc, st));
+    F.coo_nz = rptr[n];
+  }
+  return hipStreamSynchronize(st);
+}
+
+hipError_t dev_map_values(DeviceFactor& F, const double* d_val_in, hipStream_t st) {
+  if (F.nscatter_coo > 0)
+    hipLaunchKernelGGL(k_map_values, dim3(unsigned((F.nscatter_coo + 255) / 256)), dim3(256), 0, st, F.nscatter_coo,
+                       F.mv_ptr, F.mv_src, d_val_in, F.valcsc);
+  return hipGetLastError();
+}
+
+hipError_t dev_residual(DeviceFactor& F, int n, int nrhs, const double* d_x, int ldx, const double* d_b, int ldb,
+                        double* d_r, int ldr, hipStream_t st) {
+  for (int k = 0; k < nrhs; ++k)
+    hipLaunchKernelGGL(k_coo_residual, dim3((n + 255) / 256), dim3(256), 0, st, n, F.rs_ptr, F.rs_col, F.rs_src,
+                       F.coo_val, d_x + int64_t(k) * ldx, d_b + int64_t(k) * ldb, d_r + int64_t(k) * ldr);
+  return hipGetLastError();
 }
 
 // Fronts that go through k_front_tpp instead of the blocked kernels (host decision, gsls_api.cpp): a flag per

@@ -131,6 +131,17 @@ struct DeviceFactor {
   int64_t Lf_elems = 0, Lb_elems = 0;
   double* xs = nullptr;           // forward result of the covered fronts by pivot slot (job ALL)
   int32_t* gvar = nullptr;        // pivot slot -> variable, refreshed by every factorization
+  // the caller's own matrix (gsls_set_coo): value map by destination, and the full symmetric matrix by rows
+  int64_t coo_ne = 0, coo_nz = 0, nscatter_coo = 0;  // entries of the caller's storage / of the full symmetric row structure
+  int64_t* mv_ptr = nullptr;       // per CSC value position: range in mv_src
+  int32_t* mv_src = nullptr;       // ... the caller's entries that are placed / added there, in entry order
+  int64_t* rs_ptr = nullptr;       // per row of A: range in rs_col / rs_src
+  int32_t* rs_col = nullptr;
+  int32_t* rs_src = nullptr;       // ... the caller's entry that holds the value
+  double* coo_val = nullptr;       // the caller's values of the last gsls_factor_coo
+  double* valcsc = nullptr;        // the mapped CSC values
+  double* rbuf = nullptr;          // x, b, r staging of gsls_residual
+  int64_t rbuf_cap = 0;
   // numeric
   double* L = nullptr;
   double* Linv = nullptr;        // Cholesky only: L11^-T of every 64-column block, nblk64 x 64 x 64
@@ -144,6 +155,7 @@ struct DeviceFactor {
   double* xp = nullptr;        // permuted solution / rhs workspace (n * nrhs_cap)
   double* cvec = nullptr;      // per-node contribution vectors for the forward solve
   double* xhost = nullptr;     // staging for host x
+  int64_t xhost_cap = 0;
   int32_t* faillist = nullptr; // analyse-time positions of pivots that failed in the last pass
   int32_t* stat = nullptr;     // [0] first failing pivot position+1 (posdef) / flag, [1] zero pivots,
                                // [2] num_neg, [3] num_two, [4] delays
@@ -157,6 +169,15 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
 void dev_free(DeviceFactor& F);
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
                       const double* d_scale, double small, double u, hipStream_t st, bool use_tiny = false);
+hipError_t dev_set_coo(DeviceFactor& F, int n, int64_t nzcsc, int64_t ne, const int32_t* row, const int32_t* col,
+                       const int32_t* map, hipStream_t st);
+hipError_t dev_map_values(DeviceFactor& F, const double* d_val_in, hipStream_t st);
+hipError_t dev_residual(DeviceFactor& F, int n, int nrhs, const double* d_x, int ldx, const double* d_b, int ldb,
+                        double* d_r, int ldr, hipStream_t st);
+void dev_free_coo(DeviceFactor& F);
+// x += r ; *out (device, 8 bytes, zeroed by the call) = max |v_i| as the bit pattern of a non-negative double
+hipError_t dev_vec_add(int n, double* d_x, const double* d_r, hipStream_t st);
+hipError_t dev_max_abs(int n, const double* d_v, unsigned long long* d_out, hipStream_t st);
 hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
 hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,

@@ -23,6 +23,7 @@ module GALAHAD_GSLS_double
   public :: gsls_keep, gsls_options, gsls_inform
   public :: GSLS_initialize, GSLS_analyse, GSLS_factor, GSLS_solve, GSLS_solve_mult
   public :: GSLS_enquire_posdef, GSLS_enquire_indef, GSLS_alter, GSLS_free
+  public :: GSLS_set_coo, GSLS_factor_coo, GSLS_residual, GSLS_get_order, GSLS_solve_ir
 
   integer, parameter :: wp = c_double
   integer, parameter :: long = c_int64_t
@@ -130,6 +131,48 @@ module GALAHAD_GSLS_double
       type(c_ptr), value :: piv_order, d
       type(gsls_inform), intent(out) :: inform
     end function
+    integer(c_int) function c_gsls_set_coo(handle, ne, row, col, map) bind(C, name='gsls_set_coo')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t
+      type(c_ptr), value :: handle
+      integer(c_int64_t), value :: ne
+      type(c_ptr), value :: row, col
+      integer(c_int32_t), intent(in) :: map(*)
+    end function
+    integer(c_int) function c_gsls_factor_coo(handle, posdef, val, scale, options, inform) &
+        bind(C, name='gsls_factor_coo')
+      import :: c_ptr, c_int, c_int32_t, c_double, gsls_options, gsls_inform
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: posdef
+      real(c_double), intent(in) :: val(*)
+      type(c_ptr), value :: scale
+      type(gsls_options), intent(in) :: options
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_residual(handle, nrhs, x, ldx, b, ldb, r, ldr, inform) &
+        bind(C, name='gsls_residual')
+      import :: c_ptr, c_int, c_int32_t, c_double, gsls_inform
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: nrhs, ldx, ldb, ldr
+      real(c_double), intent(in) :: x(*), b(*)
+      real(c_double), intent(out) :: r(*)
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_solve_ir(handle, x, max_ref, res_abs, res_rel, iters, options, inform) &
+        bind(C, name='gsls_solve_ir')
+      import :: c_ptr, c_int, c_int32_t, c_double, gsls_options, gsls_inform
+      type(c_ptr), value :: handle
+      real(c_double), intent(inout) :: x(*)
+      integer(c_int32_t), value :: max_ref
+      real(c_double), value :: res_abs, res_rel
+      integer(c_int32_t), intent(out) :: iters
+      type(gsls_options), intent(in) :: options
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_get_order(handle, order) bind(C, name='gsls_get_order')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: handle
+      integer(c_int32_t), intent(out) :: order(*)
+    end function
     integer(c_int) function c_gsls_alter(handle, d, inform) bind(C, name='gsls_alter')
       import :: c_ptr, c_int, c_double, gsls_inform
       type(c_ptr), value :: handle
@@ -233,6 +276,75 @@ contains
     integer(c_int) :: rc
     rc = c_gsls_alter(keep%handle, d, inform)
   end subroutine GSLS_alter
+
+  ! the caller's COORDINATE storage (row, col optional) and SLS's map from its entries to the sorted
+  ! lower-by-columns values (src/sls/sls.f90:8409-8578) are handed to the backend once, after GSLS_analyse
+  subroutine GSLS_set_coo(ne, map, keep, inform, row, col)
+    integer, intent(in) :: ne
+    integer, intent(in) :: map(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_inform), intent(inout) :: inform
+    integer, optional, target, intent(in) :: row(:), col(:)
+    integer(c_int) :: rc
+    type(c_ptr) :: rp, cp
+    rp = c_null_ptr ; cp = c_null_ptr
+    if (present(row) .and. present(col)) then
+      rp = c_loc(row) ; cp = c_loc(col)
+    end if
+    rc = c_gsls_set_coo(keep%handle, int(ne, c_int64_t), rp, cp, map)
+    inform%flag = int(rc)
+  end subroutine GSLS_set_coo
+
+  ! SLS_factorize without the host scatter: val in the caller's entry order (sls.f90:4113-4150 + 4273-4297)
+  subroutine GSLS_factor_coo(posdef, val, keep, options, inform, scale)
+    logical, intent(in) :: posdef
+    real(wp), intent(in) :: val(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    type(gsls_inform), intent(out) :: inform
+    real(wp), optional, target, intent(in) :: scale(:)
+    integer(c_int) :: rc
+    type(c_ptr) :: sp
+    sp = c_null_ptr
+    if (present(scale)) sp = c_loc(scale)
+    rc = c_gsls_factor_coo(keep%handle, merge(1_c_int32_t, 0_c_int32_t, posdef), val, sp, options, inform)
+  end subroutine GSLS_factor_coo
+
+  ! r = b - A x with the matrix of the last GSLS_factor_coo (the residual step of SLS_solve_ir, sls.f90:4826-4934)
+  subroutine GSLS_residual(x, b, r, keep, inform)
+    real(wp), intent(in) :: x(:), b(:)
+    real(wp), intent(out) :: r(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_inform), intent(out) :: inform
+    integer(c_int) :: rc
+    integer(c_int32_t) :: n
+    n = int(max(keep%n, 1), c_int32_t)
+    rc = c_gsls_residual(keep%handle, 1_c_int32_t, x, n, b, n, r, n, inform)
+  end subroutine GSLS_residual
+
+  ! SLS_solve_ir (sls.f90:4770-4949) as one call: x = b on entry, the refined solution on exit
+  subroutine GSLS_solve_ir(x, max_refinements, residual_absolute, residual_relative, iterations, keep, options, inform)
+    real(wp), intent(inout) :: x(:)
+    integer, intent(in) :: max_refinements
+    real(wp), intent(in) :: residual_absolute, residual_relative
+    integer, intent(out) :: iterations
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    type(gsls_inform), intent(out) :: inform
+    integer(c_int) :: rc
+    integer(c_int32_t) :: it
+    rc = c_gsls_solve_ir(keep%handle, x, int(max_refinements, c_int32_t), residual_absolute, residual_relative, &
+                         it, options, inform)
+    iterations = int(it)
+  end subroutine GSLS_solve_ir
+
+  ! order(i) = position of variable i in the pivot sequence the factors are in
+  subroutine GSLS_get_order(order, keep)
+    integer, intent(out) :: order(:)
+    type(gsls_keep), intent(inout) :: keep
+    integer(c_int) :: rc
+    rc = c_gsls_get_order(keep%handle, order)
+  end subroutine GSLS_get_order
 
   subroutine GSLS_free(keep, status)
     type(gsls_keep), intent(inout) :: keep

@@ -234,6 +234,15 @@ class SLS:
                                 self.ORDER.ctypes.data_as(_lib.p_i32), C.byref(self.opts),
                                 C.byref(ginf))
         self._copy_inform(inform, ginf, flag)
+        if flag >= 0:
+            # the user's storage and SLS's map stay with the backend (HBM): SLS_factorize's scatter loop and the
+            # refinement residual run on the device (include/gsls.h, gsls_set_coo)
+            self._coo = (np.ascontiguousarray(r, dtype=np.int32), np.ascontiguousarray(c, dtype=np.int32))
+            f2 = lib.gsls_set_coo(self.handle, len(self.MAPS), self._coo[0].ctypes.data_as(C.c_void_p),
+                                  self._coo[1].ctypes.data_as(C.c_void_p),
+                                  np.ascontiguousarray(self.MAPS, dtype=np.int32).ctypes.data_as(C.c_void_p))
+            if f2 < 0:
+                inform.status = _status_from_flag(f2)
 
     def _copy_control(self, control):
         """SLS_copy_control_to_ssids, src/sls/sls.f90:1385-1439"""
@@ -282,12 +291,14 @@ class SLS:
             inform.status = GALAHAD_error_call_order
             return
         self._copy_control(control)
-        VAL = self.scatter_values(matrix)
+        v = np.ascontiguousarray(matrix.val[: len(self.MAPS)], dtype=np.float64)
         ginf = Inform()
-        flag = lib.gsls_factor(self.handle, 1 if self.must_be_definite else 0,
-                               VAL.ctypes.data_as(C.c_void_p), None, C.byref(self.opts),
-                               C.byref(ginf))
+        flag = lib.gsls_factor_coo(self.handle, 1 if self.must_be_definite else 0,
+                                   v.ctypes.data_as(C.c_void_p), None, C.byref(self.opts), C.byref(ginf))
         self._copy_inform(inform, ginf, flag)
+        if flag >= 0:      # the order the factors are in (pre-ordering, order repair, learned pivots): what PERM reports
+            lib.gsls_get_order(self.handle, self.ORDER.ctypes.data_as(_lib.p_i32))
+        self._resid_on_device = flag >= 0
 
     # -- SLS_solve (with iterative refinement, sls.f90:4692-4963 / 4967-5270) -----------------------
     def _backend_solve(self, X, job, inform):
@@ -319,12 +330,39 @@ class SLS:
                 np.subtract.at(RES[:, k], c[off], v[off] * X[r[off], k])
         return RES
 
+    def _residual_dev(self, matrix, B, X):
+        """RES = B - A X on the device (gsls_residual) -- the matrix of the last factorization; falls back to the
+        host loop when the backend does not hold it"""
+        if not getattr(self, "_resid_on_device", False):
+            return self._residual(matrix, B, X)
+        X = np.asfortranarray(X, dtype=np.float64)
+        B = np.asfortranarray(B, dtype=np.float64)
+        R = np.empty_like(B, order="F")
+        nrhs = 1 if X.ndim == 1 else X.shape[1]
+        ginf = Inform()
+        flag = lib.gsls_residual(self.handle, nrhs, X.ctypes.data_as(C.c_void_p), self.n,
+                                 B.ctypes.data_as(C.c_void_p), self.n, R.ctypes.data_as(C.c_void_p), self.n,
+                                 C.byref(ginf))
+        if flag < 0:
+            return self._residual(matrix, B, X)
+        return R
+
     def solve(self, matrix, X, control, inform):
         """X holds b on entry, x on exit (returned)."""
         inform.status = GALAHAD_ok
         X = np.array(X, dtype=np.float64, order="F")
         if control.max_iterative_refinements <= 0:
             return self._backend_solve(X, 0, inform)
+        if X.ndim == 1 and getattr(self, "_resid_on_device", False):
+            # the whole refinement loop on the device (gsls_solve_ir = SLS_solve_ir, sls.f90:4770-4949)
+            ginf, it = Inform(), _lib.i32(0)
+            flag = lib.gsls_solve_ir(self.handle, X.ctypes.data_as(C.c_void_p), control.max_iterative_refinements,
+                                     control.acceptable_residual_absolute, control.acceptable_residual_relative,
+                                     C.byref(it), C.byref(self.opts), C.byref(ginf))
+            inform.status = _status_from_flag(flag)
+            inform.gsls_inform = ginf.as_dict()
+            inform.iterative_refinements = it.value
+            return X
         B = X.copy()
         RES = X.copy()
         X = np.zeros_like(B)
@@ -336,7 +374,7 @@ class SLS:
                 return X
             X = X + RES
             if it < control.max_iterative_refinements:
-                RES = self._residual(matrix, B, X)
+                RES = self._residual_dev(matrix, B, X)
             residual = np.abs(RES).max(axis=0)
             if np.all(residual < np.maximum(control.acceptable_residual_absolute,
                                             control.acceptable_residual_relative * residual_zero)):
@@ -356,6 +394,20 @@ class SLS:
             if self.must_be_definite:
                 return X
             return self._backend_solve(X, 2, inform)
+        if part == "S":
+            # L sqrt(D): for a Cholesky factor that IS L (sls.f90:6837); otherwise the MA57 arm's recipe
+            # (sls.f90:6635-6672): y = L^-1 x, z = D^-1 y, x_i = sign * sqrt|z_i| sqrt|y_i|, which needs
+            # z_i and y_i of one sign (a positive definite D) -- anything else is GALAHAD_error_inertia
+            Y = self._backend_solve(X, 1, inform)
+            if self.must_be_definite or inform.status != GALAHAD_ok:
+                return Y
+            Z = self._backend_solve(Y.copy(), 2, inform)
+            if inform.status != GALAHAD_ok:
+                return Z
+            if np.any((Z == 0.0) != (Y == 0.0)) or np.any(Z * Y < 0.0):
+                inform.status = GALAHAD_error_inertia
+                return Z
+            return np.sign(Z) * np.sqrt(np.abs(Z)) * np.sqrt(np.abs(Y))
         inform.status = GALAHAD_unavailable_option
         return X
 

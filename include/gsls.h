@@ -151,6 +151,35 @@ int gsls_factor(void* handle, int32_t posdef, const double* val, const double* s
 int gsls_factor_dev(void* handle, int32_t posdef, const double* d_val, const double* d_scale,
                     const gsls_options* options, gsls_inform* inform);
 
+/* ---- the caller's own matrix on the device ------------------------------------
+ * SLS keeps the user's matrix (COORDINATE storage: row, col, val of its lower triangle) and a map MAPS from its
+ * entries to the sorted lower-CSC values the backend factorizes (SLS_coord_to_sorted_csr, src/sls/sls.f90:8409-8578:
+ * map[l] = k > 0: val[l] is placed at position k, k < 0: added to position -k, 0: entry out of range, ignored).
+ * With the map resident in HBM, SLS_factorize's host loop over the entries (sls.f90:4113-4150) becomes one
+ * transfer of val[ne] and one kernel, and the residual b - A x of SLS's iterative refinement
+ * (sls.f90:4826-4934) a sparse matrix-vector product on the device.
+ * gsls_set_coo: after gsls_analyse; row / col may be NULL (then gsls_residual is unavailable).  1-based indices. */
+int gsls_set_coo(void* handle, int64_t ne, const int32_t* row, const int32_t* col, const int32_t* map);
+
+/* replaces the value scatter + ssids_factor pair of SLS_factorize: val[ne] in the order of the map (host memory;
+ * _dev: HBM).  Duplicates are summed in entry order, as the reference does. */
+int gsls_factor_coo(void* handle, int32_t posdef, const double* val, const double* scale,
+                    const gsls_options* options, gsls_inform* inform);
+int gsls_factor_coo_dev(void* handle, int32_t posdef, const double* d_val, const double* d_scale,
+                        const gsls_options* options, gsls_inform* inform);
+
+/* r = b - A x for nrhs vectors (host memory, column-major), A = the matrix of the last gsls_factor_coo
+ * (the residual step of SLS_solve_ir, sls.f90:4826-4934).  Row by row in a fixed order: reproducible. */
+int gsls_residual(void* handle, int32_t nrhs, const double* x, int32_t ldx, const double* b, int32_t ldb,
+                  double* r, int32_t ldr, gsls_inform* inform);
+
+/* The whole of SLS_solve_ir (src/sls/sls.f90:4770-4949) on the device, for one right-hand side and the matrix of the
+ * last gsls_factor_coo: x holds b on entry and the refined solution on exit (host memory), *iterations the value
+ * SLS reports as inform%iterative_refinements.  Same recurrence, same stopping test
+ * (max|r| < max(residual_absolute, residual_relative * max|b|)), residuals formed as gsls_residual does. */
+int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double residual_absolute,
+                  double residual_relative, int32_t* iterations, const gsls_options* options, gsls_inform* inform);
+
 /* ---- solve --------------------------------------------------------------------------------------- */
 
 /* replaces ssids_solve(x, ...) / ssids_solve(nrhs, x, ldx, ..., job)

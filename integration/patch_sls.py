@@ -50,15 +50,30 @@ ARMS = [
                             data%gsls_inform, data%ORDER )
          CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
          IF ( inform%status /= GALAHAD_ok ) GO TO 800
+!  the user's storage and the map MAPS stay with the backend (HBM): the value scatter of SLS_factorize and the
+!  residual of SLS_solve_ir run there
+         IF ( SMT_get( matrix%type ) == 'COORDINATE' ) THEN
+           CALL GSLS_set_coo( data%matrix_ne, data%MAPS, data%gsls_keep,        &
+                              data%gsls_inform, matrix%ROW, matrix%COL )
+         ELSE
+           CALL GSLS_set_coo( data%matrix_ne, data%MAPS, data%gsls_keep,        &
+                              data%gsls_inform )
+         END IF
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+         IF ( inform%status /= GALAHAD_ok ) GO TO 800
 
 """,
     # 3: SLS_factorize (:4273-4297)
     """       CASE ( 'gsls' )
          CALL SLS_copy_control_to_gsls( control, data%gsls_options )
          CALL CPU_time( time ) ; CALL CLOCK_time( clock )
-         CALL GSLS_factor( data%must_be_definite, data%matrix%VAL,              &
-                           data%gsls_keep, data%gsls_options, data%gsls_inform )
+         CALL GSLS_factor_coo( data%must_be_definite,                           &
+                               matrix%VAL( : data%matrix_ne ), data%gsls_keep,  &
+                               data%gsls_options, data%gsls_inform )
          CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+!  the order the factors are in (pre-ordering, repaired and learned pivot sequence): what SLS_enquire reports
+         IF ( inform%status == GALAHAD_ok )                                     &
+           CALL GSLS_get_order( data%ORDER, data%gsls_keep )
 
 """,
     # 4: SLS_solve_one_rhs (:5392-5397)
@@ -118,7 +133,7 @@ ARMS = [
        END IF
 
 """,
-    # 9: SLS_part_solve (:6886-6920; the ssids arm returns "unavailable", gsls implements L, D, U)
+    # 9: SLS_part_solve (:6886-6920; the ssids arm returns "unavailable", gsls implements L, D, U and S)
     """     CASE ( 'gsls' )
        CALL CPU_time( time ) ; CALL CLOCK_time( clock )
        IF ( part == 'L' ) THEN
@@ -137,6 +152,35 @@ ARMS = [
          CALL GSLS_solve( X( : data%n ), data%gsls_keep, data%gsls_options,     &
                           data%gsls_inform, job = 3 )
          CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+       ELSE IF ( part == 'S' ) THEN
+!  L sqrt(D): a Cholesky factor is L sqrt(D) already; otherwise as the MA57 arm does
+         CALL GSLS_solve( X( : data%n ), data%gsls_keep, data%gsls_options,     &
+                          data%gsls_inform, job = 1 )
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+         IF ( inform%status == GALAHAD_ok .AND. .NOT. data%must_be_definite ) THEN
+           CALL SPACE_resize_array( data%n, data%WORK,                         &
+                                    inform%status, inform%alloc_status )
+           IF ( inform%status /= GALAHAD_ok ) GO TO 900
+           data%WORK( : data%n ) = X( : data%n )
+           CALL GSLS_solve( X( : data%n ), data%gsls_keep, data%gsls_options,   &
+                            data%gsls_inform, job = 2 )
+           CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+           IF ( inform%status /= GALAHAD_ok ) GO TO 900
+           DO i = 1, data%n
+             IF ( X( i ) == 0.0_wp .AND. data%WORK( i ) == 0.0_wp ) CYCLE
+             IF ( ( X( i ) == 0.0_wp .AND. data%WORK( i ) /= 0.0_wp ) .OR.     &
+                  ( X( i ) /= 0.0_wp .AND. data%WORK( i ) == 0.0_wp ) .OR.     &
+                  ( X( i ) > 0.0_wp .AND. data%WORK( i ) < 0.0_wp ) .OR.       &
+                  ( X( i ) < 0.0_wp .AND. data%WORK( i ) > 0.0_wp ) ) THEN
+               inform%status = GALAHAD_error_inertia ; GO TO 900
+             END IF
+             IF ( X( i ) > 0.0_wp ) THEN
+               X( i ) = SQRT( X( i ) ) * SQRT( data%WORK( i ) )
+             ELSE
+               X( i ) = - SQRT( - X( i ) ) * SQRT( - data%WORK( i ) )
+             END IF
+           END DO
+         END IF
        ELSE
          inform%status = GALAHAD_unavailable_option
        END IF
@@ -144,6 +188,22 @@ ARMS = [
 
 """,
 ]
+
+# SLS_solve_ir (:4770-4949): the refinement loop -- solves, updates, residuals b - A x, norms -- as ONE backend call
+# with every vector resident in HBM; at n = 1.2e6 the host loop's ten passes over the vectors cost five times what
+# the solves do
+REFINE_ARM = """       IF ( data%solver( 1 : data%len_solver ) == 'gsls' .AND.                   &
+            SMT_get( matrix%type ) == 'COORDINATE' .AND.                        &
+            .NOT. data%explicit_scaling ) THEN
+         CALL GSLS_solve_ir( X( : n ), control%max_iterative_refinements,       &
+                             control%acceptable_residual_absolute,              &
+                             control%acceptable_residual_relative,              &
+                             inform%iterative_refinements, data%gsls_keep,      &
+                             data%gsls_options, data%gsls_inform )
+         CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
+         GO TO 900
+       END IF
+"""
 
 COPY_ROUTINES = """
 !-*-   S L S _ C O P Y _ C O N T R O L _ T O _ G S L S  S U B R O U T I N E  -*-
@@ -218,13 +278,37 @@ def main(src, dst):
     lines = open(src).read().split("\n")
     out = []
     k = 0
+    shared = refine = scatter = 0
+    refine_done = False
     for ln in lines:
         if re.fullmatch(r"\s*CASE \( 'ssids' \)", ln) and k < len(ARMS):
             out.extend(ARMS[k].rstrip("\n").split("\n"))
             out.append("")
             k += 1
         if "'ssids'" in ln and "'ma86'" in ln and "'ma77'" not in ln and "CASE (" in ln and "'gsls'" not in ln:
-            ln = ln.replace("'ssids'", "'ssids', 'gsls'")          # the shared CASE lists
+            shared += 1
+            ln = ln.replace("'ssids'", "'ssids', 'gsls'")          # the shared CASE lists (:2849 analyse, :4106 factorize)
+        # SLS_factorize: the host loop that scatters the values through MAPS (:4107-4150) is skipped for gsls --
+        # GSLS_factor_coo maps them on the device
+        if shared == 2 and scatter == 0 and ln.strip() == "data%matrix%n = matrix%n":
+            out.append(ln)
+            out.append("       IF ( data%solver( 1 : data%len_solver ) /= 'gsls' ) THEN")
+            scatter = 1
+            continue
+        if scatter == 1 and ln.strip() == "!  apply calculated scaling factors":
+            while out[-1].strip() == "":
+                out.pop()
+            out.append("       END IF")
+            out.append("")
+            scatter = 2
+        # SLS_solve_ir (:4770-4949): for gsls and COORDINATE storage the refinement loop runs on the device
+        if ln.strip() == "!  Iterative refinement is required":
+            refine += 1
+        if refine == 1 and not refine_done and ln.strip() == "n = MATRIX%n":
+            out.append(ln)
+            out.extend(REFINE_ARM.rstrip("\n").split("\n"))
+            refine_done = True
+            continue
         out.append(ln)
         if ln.strip() == "USE SPRAL_SSIDS":
             out.append("     USE GALAHAD_GSLS_double")
@@ -237,6 +321,7 @@ def main(src, dst):
         if ln.strip() == "END SUBROUTINE SLS_copy_inform_from_ssids":
             out.extend(COPY_ROUTINES.split("\n"))
     assert k == len(ARMS), "expected %d ssids arms, patched %d" % (len(ARMS), k)
+    assert shared == 2 and refine_done and scatter == 2, (shared, refine, refine_done, scatter)
     text = "\n".join(out)
     assert "USE GALAHAD_GSLS_double" in text and "TYPE ( gsls_keep ) :: gsls_keep" in text
     open(dst, "w").write(text)

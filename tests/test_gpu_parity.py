@@ -472,3 +472,164 @@ def test_all_zero_diagonal_saddle_needs_2x2_everywhere(nb):
         assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-12
     assert i.delayed_pivots == 0          # the repaired order (and the fronts that need whole-front pivoting) are remembered
     s.terminate()
+
+
+# ---- part solves, enquire, alter against the ORACLE (not against themselves) -----------------------------------
+def _oracle_for(prob, perm, nemin=32):
+    from oracle.oracle import Oracle, lower_csc
+    n, row, col, val, rhs, xs = prob
+    ptr, r, v = lower_csc(n, row, col, val)
+    o = Oracle(n, ptr, r, np.asarray(perm, dtype=np.int32), nemin=nemin)
+    return o, v
+
+
+def test_part_solves_and_enquire_match_dense_ldlt_when_pivots_are_unique():
+    """An SPD matrix through the pivoted LDL^T kernels with a given PERM: no pivoting happens, so L and D are THE
+    LDL^T factors of P A P^T (unique), computed here densely with numpy.  Every partial solve (jobs 1..4 of
+    ssids_solve, fkeep.F90:229-318; SLS_part_solve L/D/U/S, sls.f90:6551-7220) and the enquired (piv_order, D^-1)
+    (ssids_enquire_indef, fkeep.F90:321-377) must agree with them; the full solve with the C oracle's.
+    (The C oracle cannot serve for the parts: its TPP takes 2x2 pivots even on SPD matrices.)"""
+    prob = P.grid2d(17, 13)
+    n, row, col, val = prob[0], prob[1], prob[2], prob[3]
+    rng = np.random.default_rng(3)
+    perm = (rng.permutation(n) + 1).astype(np.int32)
+    s, m, c, i = run_gsls(prob, False, perm=perm)
+    assert i.status == 0 and i.negative_eigenvalues == 0 and i.two_by_two_pivots == 0
+    A = np.zeros((n, n))
+    A[row - 1, col - 1] = val
+    A = A + np.tril(A, -1).T
+    pos = s.ORDER.astype(np.int64) - 1           # variable -> pivot position (a postorder-equivalent of perm)
+    Ap = np.zeros_like(A)
+    Ap[np.ix_(pos, pos)] = A
+    Cf = np.linalg.cholesky(Ap)
+    d = np.diag(Cf) ** 2
+    Lf = Cf / np.diag(Cf)[None, :]
+    b = rng.uniform(-1, 1, n)
+    bp = np.zeros(n)
+    bp[pos] = b
+
+    def back(v):                                 # pivot order -> variable order
+        return v[pos]
+    tol = 1e-12
+    got = s.part_solve("L", b, c, i)
+    assert np.abs(got - back(np.linalg.solve(Lf, bp))).max() <= tol * np.abs(got).max()
+    got = s.part_solve("D", b, c, i)
+    assert np.abs(got - back(bp / d)).max() <= tol * np.abs(got).max()
+    got = s.part_solve("U", b, c, i)
+    assert np.abs(got - back(np.linalg.solve(Lf.T, bp))).max() <= tol * np.abs(got).max()
+    got = s._backend_solve(np.array(b), 4, i)    # D (PL)^T x = b
+    assert np.abs(got - back(np.linalg.solve(Lf.T, bp / d))).max() <= tol * np.abs(got).max()
+    got = s.part_solve("S", b, c, i)             # L sqrt(D)
+    assert i.status == 0
+    assert np.abs(got - back(np.linalg.solve(Lf, bp) / np.sqrt(d))).max() <= tol * np.abs(got).max()
+    out = s.enquire(i, want_perm=True, want_pivots=True, want_d=True)
+    assert np.array_equal(out["PIVOTS"], s.ORDER)                     # no pivoting, all 1x1
+    assert np.abs(out["D"][0] - 1.0 / d).max() <= 1e-13 * (1.0 / d).max() and not out["D"][1].any()
+    o, v = _oracle_for(prob, s.ORDER)
+    assert o.factor(v, False) == 0
+    x = s.solve(m, b, c, i)
+    assert np.abs(x - o.solve(b)).max() <= 1e-12 * np.abs(x).max()
+    s.alter_d(2.0 * out["D"], i)                 # D^-1 doubled: the solution doubles
+    x2 = s.solve(m, b, c, i)
+    assert np.abs(x2 - 2.0 * x).max() <= 1e-12 * np.abs(x2).max()
+    s.terminate()
+    o.close()
+
+
+@pytest.mark.parametrize("case", ["kkt", "rand_indef", "grid_indef"])
+def test_part_solves_compose_to_the_oracle_solution_indefinite(case):
+    """Indefinite systems: the backends choose different pivots (ours: given order first, the oracle's TPP tries 2x2
+    first), so L, D and U differ part by part -- what must agree is everything that does not depend on that
+    choice: the composition U^-1 D^-1 L^-1 b = the oracle's full solve, job 4 after job 1 likewise, the inertia
+    (Sylvester) of the enquired D, and 'S' failing with GALAHAD_error_inertia on an indefinite D."""
+    from galahad_amd import sls as S
+    prob = {"kkt": P.kkt_qpband(600, 120), "rand_indef": P.random_sparse(900, 5, seed=5, spd=False),
+            "grid_indef": P.grid2d(21, 19, shift=1.0)}[case]
+    n = prob[0]
+    s, m, c, i = run_gsls(prob, False, ordering_free=True)
+    assert i.status == 0
+    order = s.ORDER.copy()                       # the order the factors are in: the oracle gets the same
+    o, v = _oracle_for(prob, order)
+    assert o.factor(v, False) == 0
+    b = prob[4]
+    want = o.solve(b)
+    y = s.part_solve("L", b, c, i)
+    y = s.part_solve("D", y, c, i)
+    y = s.part_solve("U", y, c, i)
+    assert np.abs(y - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    y = s._backend_solve(s.part_solve("L", b, c, i), 4, i)
+    assert np.abs(y - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    assert i.negative_eigenvalues == o.stats()["num_neg"]
+    piv_o, d_o = o.enquire_indef()
+
+    def inertia(piv, d):
+        seq = np.argsort(np.abs(piv))
+        neg, k = 0, 0
+        while k < n:
+            if piv[seq[k]] > 0:
+                neg += d[0, k] < 0
+                k += 1
+            else:
+                det = d[0, k] * d[0, k + 1] - d[1, k] ** 2
+                neg += 1 if det < 0 else (2 if d[0, k] + d[0, k + 1] < 0 else 0)
+                k += 2
+        return neg
+    out = s.enquire(i, want_perm=True, want_pivots=True, want_d=True)
+    assert inertia(out["PIVOTS"], out["D"]) == inertia(piv_o, d_o) == i.negative_eigenvalues
+    # PERM is the order the factors are in: |PIVOTS| is that order up to the pivoting inside the fronts
+    assert sorted(np.abs(out["PIVOTS"])) == list(range(1, n + 1))
+    assert np.array_equal(out["PERM"], s.ORDER)
+    moved = np.abs(np.abs(out["PIVOTS"]).astype(np.int64) - out["PERM"].astype(np.int64)).max()
+    assert moved < 4096          # a pivot stays inside its front
+    s.part_solve("S", b, c, i)
+    assert i.status == S.GALAHAD_error_inertia
+    s.terminate()
+    o.close()
+
+
+def test_value_map_and_residual_on_device():
+    """gsls_set_coo / gsls_factor_coo / gsls_residual against the host loops they replace
+    (SLS_factorize's scatter sls.f90:4113-4150, SLS_solve_ir's residual sls.f90:4826-4934): duplicates summed,
+    out-of-range entries ignored, both triangles applied."""
+    import ctypes as C
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    from galahad_amd._lib import Inform, lib
+    n, row, col, val, rhs, xs = P.random_sparse(700, 6, seed=9, spd=False)
+    rng = np.random.default_rng(4)
+    # duplicates (split some values in two) and a few out-of-range entries
+    k = rng.choice(len(val), 150, replace=False)
+    row = np.concatenate([row, row[k], [0, n + 1]]).astype(np.int32)
+    col = np.concatenate([col, col[k], [1, 2]]).astype(np.int32)
+    half = 0.37 * val[k]
+    val2 = val.copy()
+    val2[k] -= half
+    val2 = np.concatenate([val2, half, [5.0, 7.0]])
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val2)
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    s.analyse(m, c, i)
+    assert i.status == 0
+    s.factorize(m, c, i)            # gsls_factor_coo
+    assert i.status == 0
+    x = s.solve(m, rhs, c, i)
+    assert P.scaled_residual(n, row[:-2], col[:-2], val2[:-2], x, rhs) <= 1e-11
+    # the same factorization from host-scattered values: bitwise the same solution
+    s2, c2, i2 = SLS(), Control(), InformSLS()
+    s2.initialize("gsls", c2, i2)
+    s2.analyse(m, c2, i2)
+    VAL = s2.scatter_values(m)
+    ginf = Inform()
+    assert lib.gsls_factor(s2.handle, 0, VAL.ctypes.data_as(C.c_void_p), None, C.byref(s2.opts), C.byref(ginf)) >= 0
+    x2 = s2._backend_solve(np.array(rhs), 0, i2)
+    assert np.array_equal(x, x2)
+    # residual on the device against the facade's host loop
+    X = rng.uniform(-1, 1, (n, 2))
+    B = rng.uniform(-1, 1, (n, 2))
+    r_dev = s._residual_dev(m, B, X)
+    r_host = s._residual(m, B, X)
+    assert np.abs(r_dev - r_host).max() <= 1e-13 * np.abs(r_host).max()
+    c.max_iterative_refinements = 2
+    xr = s.solve(m, rhs, c, i)
+    assert P.scaled_residual(n, row[:-2], col[:-2], val2[:-2], xr, rhs) <= 1e-14
+    s.terminate()
+    s2.terminate()
