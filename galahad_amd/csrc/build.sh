@@ -13,5 +13,5 @@ done
 $HIPCC $FLAGS -c $HERE/gsls_device.hip -o $HERE/obj/gsls_device.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC -shared -fPIC --offload-arch=gfx950 -o $OUT $HERE/obj/gsls_symbolic.o $HERE/obj/gsls_order.o \
-    $HERE/obj/gsls_api.o $HERE/obj/gsls_device.o
+    $HERE/obj/gsls_api.o $HERE/obj/gsls_device.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT"

@@ -5,6 +5,7 @@
 //   ssids_alter    :1347-1384                       ssids_free    :1388-1419
 // There is deliberately no CPU numeric path: without a HIP device factor/solve fail with -51.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -49,7 +50,14 @@ struct Handle {
   bool have_coo = false;          // gsls_set_coo has been called for the analysed pattern
   bool coo_uploaded = false;      // ... and its structure is on the device
   std::vector<int32_t> coo_row, coo_col, coo_map;
-  int shard_repairs = 0;          // repair rounds of the sharded path (plan_repair's pass counter)         // the device-side front flags no longer match tppvar / the current tree
+  int shard_repairs = 0;          // repair rounds of the sharded path (plan_repair's pass counter)
+  // in-library exchange (gsls_comm_*): one RCCL communicator per handle, buffers on the handle's device
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 0, comm_rank = 0;
+  double* cx_factor = nullptr;
+  double* cx_solve = nullptr;
+  int32_t* cx_fail = nullptr;     // nranks x (1 + GSLS_FAILCAP): every rank's failed pivots (all-gather)
+  int64_t cx_factor_elems = 0, cx_solve_elems = 0, cx_cut_elems = 0;         // the device-side front flags no longer match tppvar / the current tree
   int nemin = 32;
   double kt_fwd = 0, kt_diag = 0, kt_bwd = 0;
 };
@@ -243,7 +251,7 @@ void gsls_default_options(gsls_options* o) {
   o->scaling = 0;
   o->action = 1;
   o->device = -1;
-  o->use_graph = 1;
+  o->reserved2 = 0;
   o->u = 0.01;
   o->small = 1e-20;
   o->multiplier = 1.1;
@@ -266,6 +274,7 @@ int gsls_destroy(void** handle) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     dev_free(h->F);
     dev_free_coo(h->F);
+    (void)gsls_comm_destroy(h);
     for (auto& ev : h->ev)
       if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1046,7 +1055,7 @@ int gsls_shard(void* handle, int32_t nranks, int32_t rank, int64_t* xchg_factor_
     ce += cm * cm;
     ve += cm;
   }
-  if (xchg_factor_elems) *xchg_factor_elems = std::max<int64_t>(ce, 1);
+  if (xchg_factor_elems) *xchg_factor_elems = ce + 24;   // + three status blocks of 8 (k_stat_to_xchg)
   if (xchg_solve_elems) *xchg_solve_elems = std::max<int64_t>(std::max<int64_t>(ve, h->S.n), 1);
   return GSLS_SUCCESS;
 }
@@ -1191,6 +1200,245 @@ int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed_in, i
   }
   h->tpp_dirty = true;
   return gsls_shard(handle, nranks, rank, xchg_factor_elems, xchg_solve_elems);
+}
+
+// ---- the exchange inside the library: RCCL on the handle's stream (one process per GPU) ---------------------------
+// The reference drives every device from ONE ssids_factor call (fkeep.F90:99-174, contribution blocks handed over
+// through host memory, contrib.f90:20-33).  Here every rank calls the same gsls_comm_* entry point and the cut
+// roots' blocks / vectors go device to device: ncclReduce onto rank 0 (each element is non-zero on exactly one rank:
+// the owner's ingest over its xGMI links, not a ring), ncclBroadcast of the cut roots' z-vectors back.  A Fortran
+// host needs nothing but a way to hand 128 bytes (the communicator id of rank 0) to the other ranks.
+#define NCCLCHK(call)                                                            \
+  do {                                                                           \
+    ncclResult_t r__ = (call);                                                   \
+    if (r__ != ncclSuccess) { if (inform) { inform->flag = GSLS_ERROR_HIP; inform->hip_error = 10000 + int(r__); } return GSLS_ERROR_HIP; } \
+  } while (0)
+
+int gsls_comm_unique_id(char* id128) {
+  if (!id128) return GSLS_ERROR_CALL_SEQUENCE;
+  static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+  ncclUniqueId uid;
+  if (ncclGetUniqueId(&uid) != ncclSuccess) return GSLS_ERROR_HIP;
+  std::memcpy(id128, &uid, sizeof(uid));
+  return GSLS_SUCCESS;
+}
+
+static int comm_buffers(Handle* h) {
+  int64_t ce = 0, ve = 0;
+  const int f = gsls_shard(h, h->comm_ranks, h->comm_rank, &ce, &ve);
+  if (f < 0) return f;
+  int64_t cut = 0;
+  for (int c : h->S.cutroots) cut += h->S.nrow(c) - h->S.ncol(c);
+  h->cx_cut_elems = cut;
+  auto grow = [&](double*& p, int64_t& cap, int64_t need) -> bool {
+    if (cap >= need) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&p), need * sizeof(double)) != hipSuccess) return false;
+    cap = need;
+    return true;
+  };
+  if (!grow(h->cx_factor, h->cx_factor_elems, ce) || !grow(h->cx_solve, h->cx_solve_elems, std::max<int64_t>(ve, 16)))
+    return GSLS_ERROR_ALLOCATION;
+  if (!h->cx_fail && hipMalloc(reinterpret_cast<void**>(&h->cx_fail), size_t(h->comm_ranks) * (1 + GSLS_FAILCAP) * sizeof(int32_t)) != hipSuccess)
+    return GSLS_ERROR_ALLOCATION;
+  return GSLS_SUCCESS;
+}
+
+// every rank, after gsls_analyse of the same matrix (and, for an order the backend chose itself, gsls_refine_order
+// with the same values): joins the communicator and deals the subtrees
+int gsls_comm_init(void* handle, int32_t nranks, int32_t rank, const char* id128, const gsls_options* options) {
+  Handle* h = static_cast<Handle*>(handle);
+  gsls_inform* inform = nullptr;
+  if (!h || !h->analysed || !id128 || nranks < 2 || rank < 0 || rank >= nranks) return GSLS_ERROR_CALL_SEQUENCE;
+  hipError_t e = ensure_device(h, options);
+  if (e != hipSuccess) return fail_hip(h, nullptr, e);
+  DeviceGuard g(h->device);
+  if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+  ncclUniqueId uid;
+  std::memcpy(&uid, id128, sizeof(uid));
+  NCCLCHK(ncclCommInitRank(&h->comm, nranks, uid, rank));
+  h->comm_ranks = nranks;
+  h->comm_rank = rank;
+  return comm_buffers(h);
+}
+
+int gsls_comm_destroy(void* handle) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return GSLS_SUCCESS;
+  DeviceGuard g(h->device);
+  if (h->comm) (void)ncclCommDestroy(h->comm);
+  h->comm = nullptr;
+  for (void* p : {static_cast<void*>(h->cx_factor), static_cast<void*>(h->cx_solve), static_cast<void*>(h->cx_fail)})
+    if (p) (void)hipFree(p);
+  h->cx_factor = h->cx_solve = nullptr;
+  h->cx_fail = nullptr;
+  h->cx_factor_elems = h->cx_solve_elems = 0;
+  return GSLS_SUCCESS;
+}
+
+// The whole sharded factorization as ONE call per rank: subtrees, reduce of the cut roots' contribution blocks (with
+// the counters riding behind them), top part on rank 0, broadcast of the 16 status words; failed pivots are gathered
+// and repaired identically on every rank.  inform is the same on every rank (totals).
+int gsls_comm_factor_dev(void* handle, int32_t posdef, const double* d_val, const gsls_options* options,
+                         gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->comm || h->S.nranks < 2 || h->S.owner.empty()) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  gsls_options defo;
+  if (!options) {
+    gsls_default_options(&defo);
+    options = &defo;
+  }
+  const double t0 = now();
+  DeviceGuard g(h->device);
+  int total_moved = 0;
+  for (int pass = 0; pass < 60; ++pass) {
+    *inform = h->last;
+    inform->flag = GSLS_SUCCESS;
+    inform->hip_error = 0;
+    h->factored = false;
+    if (h->S.n == 0) { h->factored = true; h->posdef = posdef != 0; return GSLS_SUCCESS; }
+    if (!d_val) return inform->flag = GSLS_ERROR_VAL;
+    hipError_t e = hipSuccess;
+    if (!h->dev_ready) {
+      e = dev_upload_symbolic(h->S, h->F, h->stream);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      h->dev_ready = true;
+      h->tpp_dirty = true;
+    }
+    if (h->tpp_dirty) {
+      e = dev_set_tpp(h->S, h->F, posdef ? std::vector<int>() : tpp_nodes(h->S, h->tppvar), h->stream);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      h->tpp_dirty = false;
+    }
+    h->have_scale = false;
+    const int64_t ce = h->F.xchgC_elems;
+    e = dev_shard_factor(h->S, h->F, 1, posdef != 0, d_val, h->cx_factor, options->small, options->u, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    NCCLCHK(ncclReduce(h->cx_factor, h->cx_factor, size_t(ce + 8), ncclDouble, ncclSum, 0, h->comm, h->stream));
+    e = dev_shard_factor(h->S, h->F, 2, posdef != 0, d_val, h->cx_factor, options->small, options->u, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    NCCLCHK(ncclBroadcast(h->cx_factor + ce, h->cx_factor + ce, 16, ncclDouble, 0, h->comm, h->stream));
+    double st[16];
+    e = hipMemcpyAsync(st, h->cx_factor + ce, sizeof(st), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    h->posdef = posdef != 0;
+    inform->matrix_rank = h->S.n;
+    inform->maxfront = std::max(h->S.maxfront, h->S.maxrow);
+    inform->num_neg = inform->num_two = 0;
+    inform->num_delay = total_moved;
+    if (posdef) {
+      if (st[0] + st[8] > 0) { inform->time_factor = now() - t0; return inform->flag = GSLS_ERROR_NOT_POS_DEF; }
+    } else if (st[1] + st[9] > 0) {
+      // failed pivots somewhere: every rank contributes its list, all apply the same repair and go again
+      int32_t stat[16];
+      e = hipMemcpy(stat, h->F.stat, sizeof(stat), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      std::vector<int32_t> mine(1 + GSLS_FAILCAP, 0);
+      const int nf = (stat[4] > 0) ? std::min<int>(stat[5], FAILCAP) : 0;
+      mine[0] = nf;
+      if (nf > 0) {
+        e = hipMemcpy(mine.data() + 1, h->F.faillist, nf * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail_hip(h, inform, e);
+      }
+      int32_t* slot = h->cx_fail + size_t(h->comm_rank) * (1 + GSLS_FAILCAP);
+      e = hipMemcpyAsync(slot, mine.data(), mine.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      NCCLCHK(ncclAllGather(slot, h->cx_fail, 1 + GSLS_FAILCAP, ncclInt32, h->comm, h->stream));
+      std::vector<int32_t> all(size_t(h->comm_ranks) * (1 + GSLS_FAILCAP));
+      e = hipMemcpyAsync(all.data(), h->cx_fail, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      std::vector<int32_t> failed;
+      for (int r = 0; r < h->comm_ranks; ++r) {
+        const int32_t* p = all.data() + size_t(r) * (1 + GSLS_FAILCAP);
+        failed.insert(failed.end(), p + 1, p + 1 + std::min<int>(p[0], GSLS_FAILCAP));
+      }
+      int64_t a = 0, b = 0;
+      const int rf = gsls_shard_repair(h, int32_t(failed.size()), failed.data(), &a, &b);
+      if (rf < 0) { inform->time_factor = now() - t0; return inform->flag = rf; }
+      total_moved += int(failed.size());
+      const int cb = comm_buffers(h);
+      if (cb < 0) return inform->flag = cb;
+      continue;
+    }
+    if (!posdef) {
+      inform->num_neg = int(st[2] + st[10]);
+      inform->num_two = int(st[3] + st[11]);
+      const int nzero = int(st[4] + st[12]);
+      if (nzero > 0) {
+        inform->matrix_rank -= nzero;
+        if (!options->action) { inform->time_factor = now() - t0; return inform->flag = GSLS_ERROR_SINGULAR; }
+        inform->flag = GSLS_WARNING_FACT_SINGULAR;
+      }
+    }
+    h->factored = true;
+    inform->time_factor = now() - t0;
+    h->last = *inform;
+    return inform->flag;
+  }
+  inform->time_factor = now() - t0;
+  return inform->flag = GSLS_ERROR_UNIMPLEMENTED;
+}
+
+// One full solve (job 0, one right-hand side): d_x holds b on every rank on entry; on exit the entries of the
+// variables this rank eliminated (rank 0: also the top part's) hold the solution.  What crosses the links: the cut
+// roots' contribution vectors up (reduce onto rank 0), their z-vectors down (broadcast) -- no O(n) collective.
+int gsls_comm_solve_dev(void* handle, double* d_x, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->factored || !h->comm || h->S.nranks < 2) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  if (h->S.n == 0) return GSLS_SUCCESS;
+  if (!d_x) return inform->flag = GSLS_ERROR_X_SIZE;
+  const double t0 = now();
+  DeviceGuard g(h->device);
+  const size_t V = size_t(std::max<int64_t>(h->cx_cut_elems, 1));
+  hipError_t e = dev_shard_solve(h->S, h->F, 1, h->posdef, d_x, h->cx_solve, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  NCCLCHK(ncclReduce(h->cx_solve, h->cx_solve, V, ncclDouble, ncclSum, 0, h->comm, h->stream));
+  e = dev_shard_solve(h->S, h->F, 2, h->posdef, d_x, h->cx_solve, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  NCCLCHK(ncclBroadcast(h->cx_solve, h->cx_solve, V, ncclDouble, 0, h->comm, h->stream));
+  e = dev_shard_solve(h->S, h->F, 3, h->posdef, d_x, h->cx_solve, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  inform->time_solve = now() - t0;
+  return inform->flag;
+}
+
+// optional: every rank ends with the WHOLE solution in d_x (one O(n) all-reduce; for callers that need it)
+int gsls_comm_collect_dev(void* handle, double* d_x, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->factored || !h->comm || h->S.nranks < 2) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  *inform = h->last;
+  inform->flag = GSLS_SUCCESS;
+  if (h->S.n == 0) return GSLS_SUCCESS;
+  DeviceGuard g(h->device);
+  hipError_t e = dev_shard_solve(h->S, h->F, 4, h->posdef, d_x, h->cx_solve, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  NCCLCHK(ncclAllReduce(h->cx_solve, h->cx_solve, size_t(h->S.n), ncclDouble, ncclSum, h->comm, h->stream));
+  e = dev_shard_solve(h->S, h->F, 5, h->posdef, d_x, h->cx_solve, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  return inform->flag;
 }
 
 // owner rank of every supernode (-1: top part) and the cut roots, for callers that want to inspect

@@ -62,6 +62,17 @@ __global__ void k_scatter_a(int64_t cnt, const int64_t* __restrict__ asrc,
   }
 }
 
+// zero the contribution blocks a level is about to use (the arena is reused level by level)
+struct ZeroTask {
+  int64_t off, len;
+};
+__global__ void __launch_bounds__(256)
+k_zero_tasks(const ZeroTask* __restrict__ tasks, double* __restrict__ C) {
+  const ZeroTask t = tasks[blockIdx.x];
+  double* p = C + t.off;
+  for (int64_t i = threadIdx.x; i < t.len; i += 256) p[i] = 0.0;
+}
+
 // =================================================================================================
 // extend-add: every parent pulls its children's contribution blocks, one child after the other
 // (deterministic summation order, no atomics).
@@ -2883,6 +2894,40 @@ __global__ void k_xmask(int n, const int32_t* __restrict__ posowner, double* __r
   if (mode == 0) { if (o < 0) xp[i] = xq[i]; }
   else if (!(o == me || (o < 0 && me == 0))) xp[i] = 0.0;
 }
+// z-vectors of the cut roots: the ancestors' part of the solution that the subtree below a cut root needs --
+// rows n..m-1 of the root's front, which (elimination-tree property) cover every top-part position any front of that
+// subtree refers to.  dir 0 (rank 0, after the top part's backward sweep): buf[dst + i] = xp[rlist[src + i]] for every
+// cut root; dir 1 (owner): xp[rlist[src + i]] = buf[dst + i] for the roots this rank owns.
+__global__ void k_zvec(const Segment* __restrict__ seg, const int32_t* __restrict__ rlist, double* __restrict__ xp,
+                       double* __restrict__ buf, int dir, int me) {
+  const Segment sg = seg[blockIdx.y];
+  if (dir == 1 && sg.owner != me) return;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < sg.len; i += int64_t(gridDim.x) * blockDim.x) {
+    if (dir == 0) buf[sg.dst + i] = xp[rlist[sg.src + i]];
+    else xp[rlist[sg.src + i]] = buf[sg.dst + i];
+  }
+}
+// x[var] = xp[pos] for the positions this rank computed (its subtrees; rank 0 also the top part)
+__global__ void k_permute_out_owned(int n, const int32_t* __restrict__ invp, const int32_t* __restrict__ posowner,
+                                    int me, const double* __restrict__ xp, double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = posowner[i];
+  if (o == me || (o < 0 && me == 0)) x[invp[i]] = xp[i];
+}
+// the factorization counters of this rank as doubles behind the contribution blocks of the exchange buffer, so that
+// ONE reduction carries data and status: [0] ranks that met a non-positive pivot (posdef), [1] failed columns
+// (delays), [2] negative pivots, [3] 2x2 pivots, [4] zero pivots
+__global__ void k_stat_to_xchg(const int32_t* __restrict__ stat, double* __restrict__ out,
+                               const double* __restrict__ minus) {     // minus: an earlier snapshot to subtract, or null
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int neg = stat[2];
+  for (int b = 0; b < STAT_BINS; ++b) neg += stat[16 + b];
+  double v[8] = {(stat[0] != INT_MAX) ? 1.0 : 0.0, double(stat[4]), double(neg), double(stat[3]), double(stat[1]), 0.0, 0.0, 0.0};
+  for (int k = 0; k < 8; ++k) out[k] = v[k] - (minus ? minus[k] : 0.0);
+  if (minus && out[0] < 0.0) out[0] = 0.0;
+}
+
 // D solve restricted to the positions of one owner class (sel = rank, or -1 for the top part)
 __global__ void k_solve_diag_owned(int n, const double* __restrict__ D, const int32_t* __restrict__ gperm,
                                    const int32_t* __restrict__ posowner, int sel, double* __restrict__ xp) {
@@ -2928,8 +2973,8 @@ void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.tftasks, F.asrc, F.adst, F.arow,
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
-                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.posowner, F.tppflag, F.tpplist,
-                  F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
+                  F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
+                  F.cztasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   // the caller's matrix (gsls_set_coo) depends on the pattern only, not on the elimination order: it survives
@@ -3450,11 +3495,22 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     F.nseg = int(sc.size());
     F.xchgC_elems = oc;
     F.xchgV_elems = ov;
-    Segment *d1 = nullptr, *d2 = nullptr;
+    std::vector<Segment> sz;
+    {
+      int64_t oz = 0;
+      for (int c : S.cutroots) {
+        const int64_t cm = S.nrow(c) - S.ncol(c);
+        sz.push_back(Segment{S.rptr[c] + S.ncol(c), oz, cm, S.owner[c], 0});
+        oz += cm;
+      }
+    }
+    Segment *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
     HIPCHK(upload(d1, sc, st));
     HIPCHK(upload(d2, sv, st));
+    HIPCHK(upload(d3, sz, st));
     F.segC = d1;
     F.segV = d2;
+    F.segZ = d3;
     std::vector<int32_t> po(S.n, -1);
     for (int s = 0; s < nn; ++s)
       for (int p2 = S.sptr[s]; p2 < S.sptr[s + 1]; ++p2) po[p2] = S.owner[s];
@@ -3487,6 +3543,21 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   F.nblk64 = nblk64;
   F.L_elems = S.loff[nn];
   F.C_elems = S.coff[nn];
+  {
+    std::vector<ZeroTask> zt;
+    F.cz_begin.assign(S.nlevels, 0);
+    F.cz_cnt.assign(S.nlevels, 0);
+    const int64_t chunk = int64_t(1) << 16;        // 512 KB per workgroup
+    for (int l = 0; l < S.nlevels; ++l) {
+      F.cz_begin[l] = int(zt.size());
+      for (int r = S.czptr[l]; r < S.czptr[l + 1]; ++r)
+        for (int64_t o = 0; o < S.czlen[r]; o += chunk) zt.push_back(ZeroTask{S.czoff[r] + o, std::min(chunk, S.czlen[r] - o)});
+      F.cz_cnt[l] = int(zt.size()) - F.cz_begin[l];
+    }
+    ZeroTask* d = nullptr;
+    HIPCHK(upload(d, zt, st));
+    F.cztasks = d;
+  }
   F.cvec_elems = S.cmapptr[nn];
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.L), std::max<int64_t>(F.L_elems, 1) * sizeof(double)));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.C), std::max<int64_t>(F.C_elems, 1) * sizeof(double)));
@@ -3514,13 +3585,16 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
 // -------------------------------------------------------------------------------------------------
 template <bool POSDEF>
 static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::vector<LevelPlan>& plan,
-                                double small, double u, hipStream_t st, int which = 0) {
+                                double small, double u, hipStream_t st, int which = 0, bool zero_c = true) {
   const size_t lds_diag = std::max(sizeof(Stage<PR>), sizeof(double) * LDP * NB);
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
   const size_t lds_chol = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * NB);
   const size_t lds_pchol = std::max(sizeof(Stage<RB, CK>), sizeof(double) * (2 * NB * RBP));
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
+    if (zero_c && F.cz_cnt[l] > 0)     // the contribution blocks this level's fronts own (arena space is reused)
+      hipLaunchKernelGGL(k_zero_tasks, dim3(F.cz_cnt[l]), dim3(256), 0, st,
+                         static_cast<const ZeroTask*>(F.cztasks) + F.cz_begin[l], F.C);
     if (lp.pull_cnt > 0)
       hipLaunchKernelGGL(k_assemble_pull, dim3(lp.pull_cnt), dim3(256), 0, st,
                          static_cast<const PullTask*>(F.pulltasks) + lp.pull_begin,
@@ -3806,7 +3880,6 @@ static hipError_t ensure_linv(DeviceFactor& F) {
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
                       const double* d_scale, double small, double u, hipStream_t st, bool use_tiny) {
   HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
-  HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
   HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
   static const std::vector<int32_t> init = [] { std::vector<int32_t> v(NSTAT, 0); v[0] = INT_MAX; return v; }();
   HIPCHK(hipMemcpyAsync(F.stat, init.data(), NSTAT * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -4025,7 +4098,6 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
   if (!F.sharded) return hipErrorInvalidValue;
   if (phase == 1) {
     HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
-    HIPCHK(hipMemsetAsync(F.C, 0, std::max<int64_t>(F.C_elems, 1) * sizeof(double), st));
     HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
     static const std::vector<int32_t> init = [] { std::vector<int32_t> v(NSTAT, 0); v[0] = INT_MAX; return v; }();
     HIPCHK(hipMemcpyAsync(F.stat, init.data(), NSTAT * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -4040,30 +4112,40 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
                           : factor_levels<false>(S, F, F.planA, small, u, st, 1);
     if (e != hipSuccess) return e;
     launch_segments(F, F.segC, F.C, d_xchg, 0, st);
+    hipLaunchKernelGGL(k_stat_to_xchg, dim3(1), dim3(64), 0, st, F.stat, d_xchg + F.xchgC_elems, static_cast<const double*>(nullptr));
+    hipLaunchKernelGGL(k_stat_to_xchg, dim3(1), dim3(64), 0, st, F.stat, d_xchg + F.xchgC_elems + 16, static_cast<const double*>(nullptr));   // own copy (not reduced)
   } else if (phase == 2) {
     if (F.myrank != 0) return hipSuccess;
     launch_segments(F, F.segC, F.C, d_xchg, 1, st);
-    return posdef ? factor_levels<true>(S, F, F.planB, small, u, st, 2)
-                  : factor_levels<false>(S, F, F.planB, small, u, st, 2);
+    hipError_t e = posdef ? factor_levels<true>(S, F, F.planB, small, u, st, 2, false)
+                          : factor_levels<false>(S, F, F.planB, small, u, st, 2, false);
+    if (e != hipSuccess) return e;
+    // the top part's own counters = rank 0's counters now minus what they were after its subtrees
+    hipLaunchKernelGGL(k_stat_to_xchg, dim3(1), dim3(64), 0, st, F.stat, d_xchg + F.xchgC_elems + 8,
+                       static_cast<const double*>(d_xchg + F.xchgC_elems + 16));
+    return hipGetLastError();
   } else {
     return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-// phase 1: permute in, forward (+D) over my subtrees, pack the cut roots' contribution vectors
-//          -> caller sums d_xchg[0 : xchgV_elems) over ranks
-// phase 2: rank 0: unpack, forward / D / backward over the top part, d_xchg[0:n) = xp; others: nothing
-//          -> caller broadcasts d_xchg[0:n) from rank 0
-// phase 3: take the top part's solution, backward over my subtrees, d_xchg[0:n) = xp masked to what
-//          this rank computed  -> caller sums d_xchg[0:n) over ranks
-// phase 4: permute out d_xchg[0:n) -> d_x
+// One full solve across the ranks; what crosses between them are the cut roots' vectors only:
+// phase 1 (all): permute in, forward (+D) over my subtrees, pack the cut roots' contribution vectors
+//          -> REDUCE d_xchg[0 : xchgV_elems) onto rank 0 (each entry is non-zero on one rank: exact, order-free)
+// phase 2 (rank 0): unpack, forward / D / backward over the top part, pack the cut roots' z-vectors (the ancestors'
+//          part of the solution below each cut) -> BROADCAST d_xchg[0 : xchgV_elems) from rank 0
+// phase 3 (all): scatter my roots' z-vectors into xp, backward over my subtrees, write the solution of the
+//          positions this rank computed into d_x (rank 0: also the top part's)
+// phase 4 (optional, O(n), for callers that want the whole vector everywhere): d_xchg[0:n) = my part, zeros elsewhere
+//          -> SUM d_xchg[0:n) over ranks, then phase 5: permute out d_xchg[0:n) -> d_x
 hipError_t dev_shard_solve(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, double* d_x,
                            double* d_xchg, hipStream_t st) {
   if (!F.sharded) return hipErrorInvalidValue;
   if (S.n == 0) return hipSuccess;
   if (F.nrhs_cap < 1) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), std::max(S.n, 1) * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));
+    HIPCHK(hipMemsetAsync(F.xp, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
     F.nrhs_cap = 1;
   }
   const int blocks = (S.n + 255) / 256;
@@ -4086,18 +4168,26 @@ hipError_t dev_shard_solve(const Symbolic& S, DeviceFactor& F, int phase, bool p
       e = posdef ? solve_sweeps<true>(S, F, F.planB, GSLS_SOLVE_JOB_ALL, F.xp, st, nullptr, -1)
                  : solve_sweeps<false>(S, F, F.planB, GSLS_SOLVE_JOB_ALL, F.xp, st, nullptr, -1);
       if (e != hipSuccess) return e;
-      HIPCHK(hipMemcpyAsync(d_xchg, F.xp, S.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (F.nseg > 0)
+        hipLaunchKernelGGL(k_zvec, dim3(8, F.nseg), dim3(256), 0, st, static_cast<const Segment*>(F.segZ), F.rlist,
+                           F.xp, d_xchg, 0, F.myrank);
       break;
     case 3:
-      hipLaunchKernelGGL(k_xmask, dim3(blocks), dim3(256), 0, st, S.n, F.posowner, F.xp, d_xchg, 0, F.myrank);
+      if (F.nseg > 0)
+        hipLaunchKernelGGL(k_zvec, dim3(8, F.nseg), dim3(256), 0, st, static_cast<const Segment*>(F.segZ), F.rlist,
+                           F.xp, d_xchg, 1, F.myrank);
       e = posdef ? solve_sweeps<true>(S, F, F.planA, GSLS_SOLVE_JOB_BWD, F.xp, st, nullptr)
                  : solve_sweeps<false>(S, F, F.planA, GSLS_SOLVE_JOB_BWD, F.xp, st, nullptr);
       if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_permute_out_owned, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.posowner, F.myrank, F.xp,
+                         d_x);
+      break;
+    case 4:
       HIPCHK(hipMemcpyAsync(d_xchg, F.xp, S.n * sizeof(double), hipMemcpyDeviceToDevice, st));
       hipLaunchKernelGGL(k_xmask, dim3(blocks), dim3(256), 0, st, S.n, F.posowner, d_xchg,
                          static_cast<const double*>(nullptr), 1, F.myrank);
       break;
-    case 4:
+    case 5:
       hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, d_xchg,
                          static_cast<const double*>(nullptr), d_x);
       break;

@@ -112,6 +112,7 @@ struct DeviceFactor {
   int64_t xchgC_elems = 0, xchgV_elems = 0;
   void* segC = nullptr;           // Segment lists for pack/unpack
   void* segV = nullptr;
+  void* segZ = nullptr;           // ... and the cut roots' rows n..m-1 in rlist (z-vectors of the backward sweep)
   int nseg = 0;
   int32_t* posowner = nullptr;    // pivot position -> owner rank of its front (-1 top)
   // wave tier of the LDL^T solves (fronts of at most 64 rows; gsls_device.hip, "WAVE TIER")
@@ -142,6 +143,9 @@ struct DeviceFactor {
   double* valcsc = nullptr;        // the mapped CSC values
   double* rbuf = nullptr;          // x, b, r staging of gsls_residual
   int64_t rbuf_cap = 0;
+  // contribution arena: (offset, length) chunks to zero before each level (Symbolic::czptr / czoff / czlen, split)
+  void* cztasks = nullptr;
+  std::vector<int> cz_begin, cz_cnt;
   // numeric
   double* L = nullptr;
   double* Linv = nullptr;        // Cholesky only: L11^-T of every 64-column block, nblk64 x 64 x 64

@@ -40,7 +40,11 @@ struct Symbolic {
   std::vector<int> cmap;
   std::vector<int64_t> loff;     // nnodes+1: element offset of each front's L block (ld = ldl[node])
   std::vector<int> ldl;          // leading dimension of each front's L block
-  std::vector<int64_t> coff;     // nnodes+1: element offset of each contribution block ((m-n)^2)
+  std::vector<int64_t> coff;     // nnodes+1: element offset of each contribution block ((m-n)^2); coff[nnodes] = arena size
+  // the contribution arena is REUSED: a block lives from its front's level to its parent's (where it is assembled),
+  // then its space goes back to a first-fit free list.  czero*: what has to be zeroed before each level runs.
+  std::vector<int> czptr;        // nlevels+1: ranges of level l are [czptr[l], czptr[l+1])
+  std::vector<int64_t> czoff, czlen;
 
   // ---- multi-GPU: subtree ownership (empty = the whole tree on one device) ----------------------
   int nranks = 1;
@@ -64,6 +68,10 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
 // work, everything above them (the top part) stays with rank 0 (cf. find_subtree_partition,
 // src/ssids/anal.f90:284-459).  Fills S.owner / S.cutroots.
 void shard_tree(Symbolic& S, int nranks);
+
+// offsets of the contribution blocks: reuse = true packs them by lifetime (single device), false lays them out one
+// after the other (multi-GPU: the cut roots' blocks must survive until the exchange)
+void layout_contrib(Symbolic& S, bool reuse);
 
 inline int align_ld(int m) { return (m + 1) & ~1; }   // 16-byte aligned columns
 

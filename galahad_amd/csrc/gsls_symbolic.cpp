@@ -449,15 +449,98 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
     }
   }
   S.loff.assign(nn + 1, 0);
-  S.coff.assign(nn + 1, 0);
   S.ldl.assign(nn, 0);
   for (int s = 0; s < nn; ++s) {
     int64_t m = S.nrow(s), ne = S.ncol(s);
     S.ldl[s] = align_ld(int(m));
     S.loff[s + 1] = S.loff[s] + int64_t(S.ldl[s]) * ne;
-    S.coff[s + 1] = S.coff[s] + (m - ne) * (m - ne);
   }
+  layout_contrib(S, true);
   return flag;
+}
+
+// Contribution blocks ((m-n)^2 doubles per front).  The reference allocates them per front and frees them as the
+// parent assembles them (assemble.hxx:347-437, BuddyAllocator.hxx); the static schedule here does the same at plan
+// time: levels run in order, a block is allocated when its front's level starts and released once its parent's level
+// has pulled it, first fit.  Without that the arena is the sum over ALL fronts -- hundreds of GB for a 3-D problem whose
+// factor itself is 30 GB.
+void layout_contrib(Symbolic& S, bool reuse) {
+  const int nn = S.nnodes;
+  S.coff.assign(nn + 1, 0);
+  S.czptr.assign(S.nlevels + 1, 0);
+  S.czoff.clear();
+  S.czlen.clear();
+  auto clen = [&](int s) { const int64_t cm = S.nrow(s) - S.ncol(s); return cm * cm; };
+  if (!reuse) {
+    for (int s = 0; s < nn; ++s) S.coff[s + 1] = S.coff[s] + clen(s);
+    if (S.nlevels > 0 && S.coff[nn] > 0) {
+      S.czoff.push_back(0);
+      S.czlen.push_back(S.coff[nn]);
+    }
+    for (int l = 1; l <= S.nlevels; ++l) S.czptr[l] = int(S.czoff.size());
+    return;
+  }
+  std::vector<std::pair<int64_t, int64_t>> freel;     // (offset, length), sorted by offset, coalesced
+  int64_t top = 0;
+  auto alloc = [&](int64_t len) -> int64_t {
+    for (size_t i = 0; i < freel.size(); ++i)
+      if (freel[i].second >= len) {
+        const int64_t off = freel[i].first;
+        if (freel[i].second == len) freel.erase(freel.begin() + i);
+        else { freel[i].first += len; freel[i].second -= len; }
+        return off;
+      }
+    if (!freel.empty() && freel.back().first + freel.back().second == top) {   // grow the last free block
+      const int64_t off = freel.back().first;
+      top = off + len;
+      freel.pop_back();
+      return off;
+    }
+    const int64_t off = top;
+    top += len;
+    return off;
+  };
+  auto release = [&](int64_t off, int64_t len) {
+    auto it = std::lower_bound(freel.begin(), freel.end(), std::make_pair(off, int64_t(0)));
+    it = freel.insert(it, std::make_pair(off, len));
+    if (it + 1 != freel.end() && it->first + it->second == (it + 1)->first) {
+      it->second += (it + 1)->second;
+      freel.erase(it + 1);
+    }
+    if (it != freel.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+      (it - 1)->second += it->second;
+      freel.erase(it);
+    }
+  };
+  std::vector<std::pair<int64_t, int64_t>> zr;
+  for (int l = 0; l < S.nlevels; ++l) {
+    zr.clear();
+    for (int i = S.lvlptr[l]; i < S.lvlptr[l + 1]; ++i) {
+      const int s = S.lvlnodes[i];
+      const int64_t len = clen(s);
+      if (len == 0) continue;
+      S.coff[s] = alloc(len);
+      zr.emplace_back(S.coff[s], len);
+    }
+    std::sort(zr.begin(), zr.end());
+    for (size_t i = 0; i < zr.size(); ++i) {          // coalesced ranges to zero before this level runs
+      if (!S.czoff.empty() && int(S.czoff.size()) > S.czptr[l] && S.czoff.back() + S.czlen.back() == zr[i].first)
+        S.czlen.back() += zr[i].second;
+      else {
+        S.czoff.push_back(zr[i].first);
+        S.czlen.push_back(zr[i].second);
+      }
+    }
+    S.czptr[l + 1] = int(S.czoff.size());
+    for (int i = S.lvlptr[l]; i < S.lvlptr[l + 1]; ++i) {
+      const int s = S.lvlnodes[i];
+      for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
+        const int c = S.clist[ci];
+        if (clen(c) > 0) release(S.coff[c], clen(c));
+      }
+    }
+  }
+  S.coff[nn] = top;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -471,6 +554,7 @@ void shard_tree(Symbolic& S, int nranks) {
   S.nranks = std::max(1, nranks);
   S.owner.assign(nn, 0);
   S.cutroots.clear();
+  layout_contrib(S, S.nranks <= 1);      // the cut roots' blocks outlive their level: no reuse across ranks
   if (S.nranks <= 1 || nn == 0) return;
   std::vector<double> w(nn, 0.0), W(nn, 0.0);
   for (int s = 0; s < nn; ++s) {

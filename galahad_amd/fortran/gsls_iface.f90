@@ -35,7 +35,7 @@ module GALAHAD_GSLS_double
     integer(c_int32_t) :: scaling = 0
     integer(c_int32_t) :: action = 1
     integer(c_int32_t) :: device = -1
-    integer(c_int32_t) :: use_graph = 1
+    integer(c_int32_t) :: reserved2 = 0
     integer(c_int32_t) :: reserved0 = 0
     real(c_double) :: u = 0.01_wp
     real(c_double) :: small = 1.0e-20_wp

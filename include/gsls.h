@@ -80,7 +80,7 @@ typedef struct gsls_options {
   int32_t scaling;         /* 0 none / user supplied `scale`                                     */
   int32_t action;          /* indefinite: continue on singularity with warning 7 (default 1)     */
   int32_t device;          /* HIP device ordinal, -1 = current device                            */
-  int32_t use_graph;       /* replay the factorization as a captured hipGraph (default 1)        */
+  int32_t reserved2;       /* (was use_graph: never implemented; launch gaps measure ~0, a graph would buy nothing) */
   int32_t reserved0;
   double u;                /* relative pivot threshold, default 0.01                             */
   double small;            /* absolute pivot tolerance, default 1e-20                            */
@@ -209,10 +209,15 @@ int gsls_alter(void* handle, const double* d, gsls_inform* inform);
  * src/ssids/anal.f90:284-459 and the region assignment :569-590.  Every rank
  * analyses the same matrix, then calls gsls_shard(nranks, rank): independent subtrees are dealt to the
  * ranks, the remaining top of the tree belongs to rank 0.  The exchange steps between the phases are
- * the caller's (RCCL all-reduce / broadcast on the buffers named below; galahad_amd/shard.py):
- *   factor: phase 1 | SUM d_xchg[0:xchg_factor_elems) | phase 2
- *   solve : phase 1 | SUM d_xchg[0:V) | phase 2 | BROADCAST d_xchg[0:n) from rank 0 | phase 3 |
- *           SUM d_xchg[0:n) | phase 4           (d_xchg has xchg_solve_elems >= max(V, n) doubles)
+ * the caller's here (galahad_amd/shard.py with torch.distributed; gsls_comm_* below does them inside the library):
+ *   factor: phase 1 | REDUCE onto rank 0 d_xchg[0:xchg_factor_elems) (blocks + counters) | phase 2 |
+ *           BROADCAST from rank 0 entries [E-24, E-8), E = xchg_factor_elems (status: 8 sums over the subtrees, then the
+ *           top part's 8:
+ *           non-positive pivots, failed columns, negative pivots, 2x2 pivots, zero pivots)
+ *   solve : phase 1 | REDUCE onto rank 0 d_xchg[0:V) | phase 2 | BROADCAST from rank 0 d_xchg[0:V) | phase 3
+ *           (V = total length of the cut roots' contribution vectors; d_x then holds the solution of the variables
+ *           this rank eliminated).  Optional, O(n): phase 4 | SUM d_xchg[0:n) | phase 5 -> the whole solution in d_x
+ *           on every rank.  d_xchg has xchg_solve_elems >= max(V, n) doubles.
  * Every summed element is non-zero on exactly one rank, so the result is exact and independent of
  * the reduction order.  inform of the factor phases carries THIS rank's num_neg / num_two / rank
  * deficiency; add them over ranks.  Delayed pivots: a factor phase that leaves inform.num_delay > 0 on
@@ -230,6 +235,25 @@ int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed, int6
                       int64_t* xchg_solve_elems);
 /* the partition: owner[nnodes] (rank, -1 = top part), number of cut roots and their 1-based indices */
 int gsls_shard_get(void* handle, int32_t* owner, int32_t* ncut, int32_t* cutroots);
+
+/* ---- multi-GPU with the exchange INSIDE the library (RCCL on the handle's stream) -----------------------------------
+ * replaces what ssids_factor / ssids_solve do for several devices in one call (src/ssids/fkeep.F90:99-174, 229-318;
+ * contribution hand-over contrib.f90:20-33).  One process per GPU; every rank makes the same calls:
+ *   rank 0: gsls_comm_unique_id(id) -> the host hands the 128 bytes to the other ranks (MPI, a file, torch.distributed)
+ *   all:    gsls_analyse (same matrix) [-> gsls_refine_order with the same values] -> gsls_comm_init(nranks, rank, id)
+ *   all:    gsls_comm_factor_dev -> gsls_comm_solve_dev ...            (any number of times)
+ * Exchanged per factorization: the cut roots' contribution blocks + 8 counters (ncclReduce onto rank 0) and 16 status
+ * words (ncclBroadcast); per solve: the cut roots' contribution vectors (ncclReduce) and their z-vectors
+ * (ncclBroadcast).  No O(n) collective on the data path; gsls_comm_collect_dev is the optional all-reduce for callers
+ * that want the whole solution on every rank.  Failed pivots: gathered (ncclAllGather) and repaired identically on
+ * every rank inside gsls_comm_factor_dev. */
+int gsls_comm_unique_id(char* id128);
+int gsls_comm_init(void* handle, int32_t nranks, int32_t rank, const char* id128, const gsls_options* options);
+int gsls_comm_factor_dev(void* handle, int32_t posdef, const double* d_val, const gsls_options* options,
+                         gsls_inform* inform);
+int gsls_comm_solve_dev(void* handle, double* d_x, gsls_inform* inform);
+int gsls_comm_collect_dev(void* handle, double* d_x, gsls_inform* inform);
+int gsls_comm_destroy(void* handle);
 
 /* ---- introspection used by the parity tests and bench (not part of the SSIDS surface) ------------ */
 

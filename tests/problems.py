@@ -125,3 +125,48 @@ def scaled_residual(n, row, col, val, x, b):
     off = r0 != c0
     np.add.at(absrow, c0[off], np.abs(val[off]))
     return np.abs(res).max() / (absrow.max() * np.abs(x).max() + np.abs(b).max())
+
+
+def grid3d_27pt_perturbed(nx, ny, nz, seed=20240105, frac=0.10):
+    """cfg5: 27-point-style stencil on an nx x ny x nz grid with a fraction `frac` of its
+    off-diagonal couplings removed and as many longer-range ones added (offsets from the distance-2 shell of the grid:
+    a uniformly random pattern of this size has no usable ordering -- the survey says so -- so "long range" means
+    beyond the stencil, not across the domain), made SPD by diagonal dominance; lower triangle, 1-based."""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(nx * ny * nz, dtype=np.int64).reshape(nz, ny, nx)
+
+    def pairs(dz, dy, dx):
+        a = idx[max(0, -dz):nz - max(0, dz), max(0, -dy):ny - max(0, dy), max(0, -dx):nx - max(0, dx)]
+        b = idx[max(0, dz):nz - max(0, -dz), max(0, dy):ny - max(0, -dy), max(0, dx):nx - max(0, -dx)]
+        return a.ravel(), b.ravel()          # b = a shifted by the offset
+
+    rows, cols, vals = [], [], []
+    near = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) > (0, 0, 0)]
+    removed = 0
+    for off in near:
+        a, b = pairs(*off)
+        keep = rng.random(len(a)) >= frac
+        removed += int((~keep).sum())
+        rows.append(np.maximum(a, b)[keep])
+        cols.append(np.minimum(a, b)[keep])
+        vals.append(np.full(int(keep.sum()), -1.0))
+    far = [(dz, dy, dx) for dz in range(-2, 3) for dy in range(-2, 3) for dx in range(-2, 3)
+           if max(abs(dz), abs(dy), abs(dx)) == 2 and (dz, dy, dx) > (0, 0, 0)]
+    per = removed // len(far) + 1
+    for off in far:
+        a, b = pairs(*off)
+        pick = rng.choice(len(a), size=min(per, len(a)), replace=False)
+        rows.append(np.maximum(a, b)[pick])
+        cols.append(np.minimum(a, b)[pick])
+        vals.append(np.full(len(pick), -0.5))
+    row, col, val = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    n = idx.size
+    absrow = np.zeros(n)
+    np.add.at(absrow, row, np.abs(val))
+    np.add.at(absrow, col, np.abs(val))
+    row = np.concatenate([row, np.arange(n)])
+    col = np.concatenate([col, np.arange(n)])
+    val = np.concatenate([val, absrow + 1.0])
+    xstar = np.ones(n)
+    rhs = sym_matvec(n, row, col, val, xstar)
+    return n, (row + 1).astype(np.int32), (col + 1).astype(np.int32), val, rhs, xstar

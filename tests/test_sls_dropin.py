@@ -67,3 +67,35 @@ def test_dropin_defaults_refinement_and_not_posdef():
     n, row, col, val, rhs, xs = P.kat_indefinite()
     r = refio.run(n, row, col, val, rhs, solver="gsls", pivot_control=2)
     assert r["status_factorize"] == -20
+
+
+@pytest.mark.gpu
+def test_cfg3_full_size_against_the_reference():
+    """BASELINE.json configs[2] at FULL size (n = 1e6, m = 2e5, order 1.2e6) against the reference itself: the CPU
+    run (GALAHAD SLS + SSIDS) is handed the elimination order the GPU run used, so fill and flop counts must be
+    identical numbers, the inertia (n, m, 0), no delayed pivots on either side, and the solutions agree to the
+    forward-error bar of SURVEY.md section 8d.  (bench.py prints the same comparison as `cpu_baseline.max_err`.)"""
+    from oracle import refio
+    if not refio.available():
+        pytest.skip("oracle/_ref/ref_driver not built")
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    n0, m0 = 1000000, 200000
+    prob = P.kkt_qpband(n0, m0)
+    n, row, col, val, rhs, xs = prob
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    c.pivot_control, c.node_amalgamation = 1, 24
+    s.analyse(m, c, i)
+    s.factorize(m, c, i)
+    assert i.status == 0, i.gsls_inform
+    x = s.solve(m, rhs, c, i)
+    order = s.ORDER.copy()
+    r = refio.run(n, row, col, val, rhs, perm=order, pivot_control=1, nemin=24, threads=16, timeout=1200)
+    assert (r["status_analyse"], r["status_factorize"], r["status_solve"]) == (0, 0, 0)
+    assert r["negative_eigenvalues"] == i.negative_eigenvalues == m0 and r["rank"] == i.rank == n
+    assert r["delayed"] == 0 and i.delayed_pivots == 0
+    assert r["entries_in_factors"] == i.entries_in_factors and r["flops_elimination"] == i.flops_elimination
+    assert np.abs(x - r["x"]).max() <= 1e-9 * np.abs(r["x"]).max()
+    assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-10
+    s.terminate()

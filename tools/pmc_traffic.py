@@ -14,9 +14,11 @@ def load(d):
 
 
 def split(rows):
+    """last step: factorization = k_iota .. before k_permute_in; solve sweep = k_permute_in .. the last solve kernel
+    (k_permute_out, or the wave tier's last backward launch, which writes the caller's vector itself)"""
     names = [r['Kernel_Name'] for r in rows]
     pin = max(i for i, n in enumerate(names) if 'k_permute_in' in n)
-    pout = max(i for i, n in enumerate(names) if 'k_permute_out' in n)
+    pout = max(i for i, n in enumerate(names) if i >= pin and ('k_permute_out' in n or 'k_wsolve_bwd' in n or 'k_solve_bwd' in n))
     iota = max(i for i, n in enumerate(names) if 'k_iota' in n and i < pin)
     return rows[iota:pin], rows[pin:pout + 1]
 
