@@ -640,50 +640,107 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 }
 
 // =================================================================================================
-// Whole-front LDL^T for TINY fronts (n <= 32 pivots, m <= 64 rows): one WAVE per front, four fronts per
-// workgroup, no LDS panel, no barriers, no MFMA.  Lane r holds row r of the front -- pivot rows and
-// contribution rows alike -- with the 32 columns in registers; the pivots run as in the serial stage of
-// k_diag_fast (given order, hinted 2x2 pivots, every pivot and multiplier tested), every row below takes
-// its update in the same instruction, and the contribution block C -= L21 D L21^T is formed from the same
-// registers.  A KKT tree is tens of thousands of such fronts: this replaces four launches of
-// workgroup-per-front kernels per level.  Any failed test only raises stat[13]; the host then repeats
-// the factorization on the workgroup path (which has the complete-pivoting fallback).
+// Whole-front LDL^T for TINY fronts (n <= 48 pivots, m <= 64 rows), assembly included: one WAVE per front, no
+// barriers, no MFMA.  The wave
+//   1. builds the front in LDS (lower triangle, packed columns): zero, the entries of A (gathered through the value
+//      map -- the rectangle in HBM is never read), then the children's contribution blocks column by column, eight
+//      columns' loads in flight at a time, children in the order the extend-add kernel uses (assemble.hxx:347-437 is
+//      the reference's version of this step);
+//   2. takes row `lane` of the front into registers -- pivot rows and contribution rows alike, all columns -- and runs
+//      the pivots as in the serial stage of k_diag_fast (given order, every pivot and multiplier tested), every row
+//      below taking its update in the same instruction;
+//   3. writes L (or, for the wave tier of the solves, the two packed images), D, and the contribution block
+//      C = (assembled part) - L21 D L21^T straight from LDS + registers: no read-modify-write in HBM.
+// A KKT tree is tens of thousands of such fronts on a handful of levels: this is ONE launch per level where the
+// workgroup kernels need five.  Any failed test only raises stat[13]; the host then repeats the factorization with
+// that front on the workgroup path (which has the pivoting fallbacks).  A front with a hinted 2x2 pivot fails at once.
 // =================================================================================================
+constexpr int TINY_N = 48;
+constexpr int TINY_CLASSES = 4;                     // unrolled for 24, 28, 32 and 48 columns
+static inline int tiny_class(int n) { return n <= 24 ? 0 : n <= 28 ? 1 : n <= 32 ? 2 : 3; }
 struct TinyFrontTask {
   int32_t n, m, ld, sptr;
   int64_t loff, coff;
-  int32_t iblk, has_contrib, node, pad;
-  int64_t lfoff, lboff;      // wave tier: the front's packed images (k_front_tiny writes them instead of the rectangle)
+  int32_t iblk, has_contrib, node, njob;
+  int64_t lfoff, lboff;      // wave tier: the front's packed images (written instead of the rectangle)
+  int64_t job0, a0;          // its PullJob range, its range of A entries (asrc / aloc)
+  int32_t acnt, pad;
 };
-__global__ void __launch_bounds__(256)
-k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restrict__ L,
-             double* __restrict__ D, double* __restrict__ C, int32_t* __restrict__ stat,
-             int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
+struct PullJob {             // up to 64 entries of one child's contribution block (lower triangle, row by row)
+  int64_t coff, mapoff;      // the child's block in the arena, its row map (cmap)
+  int32_t cm, e0;            // its order; first entry of this job: e = i (i + 1) / 2 + j, j <= i
+};
+template <int NC, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const PullJob* __restrict__ jobs,
+             const int32_t* __restrict__ cmap, const int64_t* __restrict__ asrc, const int32_t* __restrict__ aloc,
+             const double* __restrict__ val, double* __restrict__ L, double* __restrict__ D, double* __restrict__ C,
+             int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
              const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u,
-             double* __restrict__ Lf, double* __restrict__ Lbk) {
-  __shared__ double psh[4][2 * 32];   // per wave: the pivots d_k (for L*D)
+             double* __restrict__ Lf, double* __restrict__ Lbk, int tri) {
+  extern __shared__ __attribute__((aligned(16))) double fsh[];
+  __shared__ double psh[WPB][NC];     // per wave: the pivots d_k (for L*D)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ti = blockIdx.x * 4 + wave;
+  const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (ti >= ntask) return;
   const TinyFrontTask t = tasks[ti];
   if (tinyskip[t.node]) return;      // a front this kernel could not take before: it is on the workgroup path
   const int n = t.n, m = t.m, cm = m - n;
-  double* Lb = L + t.loff;
+  double* Fr = fsh + wave * tri;     // column c (rows c..m-1) at Fr[c*m - c(c+1)/2 + r]
   double* ps = psh[wave];
+  // ---- 1. the assembled front in LDS ----------------------------------------------------------------
+  {
+    // (the loads of A's entries and of the first children are issued before the triangle is zeroed)
+    double av[2];
+    int al[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = lane + 64 * q;
+      const bool ok = e < t.acnt;
+      al[q] = ok ? aloc[t.a0 + e] : -1;
+      av[q] = ok ? val[asrc[t.a0 + (ok ? e : 0)]] : 0.0;
+    }
+    const int tot = (m * (m + 1)) >> 1;
+    for (int e = lane; e < tot; e += 64) Fr[e] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (al[q] >= 0) Fr[al[q]] = av[q];
+    for (int e = lane + 128; e < t.acnt; e += 64) Fr[aloc[t.a0 + e]] = val[asrc[t.a0 + e]];
+    for (int j0 = 0; j0 < t.njob; j0 += 8) {
+      double cv[8];
+      int cd[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool on = j0 + q < t.njob;                 // uniform
+        const PullJob jb = jobs[t.job0 + (on ? j0 + q : j0)];
+        const int e = jb.e0 + lane;
+        int i = int((sqrtf(float(8 * e + 1)) - 1.0f) * 0.5f);
+        if (((i + 1) * (i + 2)) >> 1 <= e) ++i;
+        if ((i * (i + 1)) >> 1 > e) --i;
+        const int j = e - ((i * (i + 1)) >> 1);
+        const bool ok = on && i < jb.cm;
+        cv[q] = ok ? C[jb.coff + int64_t(j) * jb.cm + i] : 0.0;
+        const int pr = ok ? cmap[jb.mapoff + i] : 0;
+        const int pc = ok ? cmap[jb.mapoff + j] : 0;
+        cd[q] = ok ? pc * m - ((pc * (pc + 1)) >> 1) + pr : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)          // one child after the other: the sums do not depend on the batching
+        if (cd[q] >= 0) Fr[cd[q]] += cv[q];
+    }
+  }
   const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
-  double v[32];
+  // ---- 2. rows into registers, the pivots ----------------------------------------------------------------
+  double v[NC];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) v[k] = (lane < m && k < n && lane >= k) ? Lb[int64_t(k) * t.ld + lane] : 0.0;
+  for (int k = 0; k < NC; ++k)
+    v[k] = (lane < m && k < n && lane >= k) ? Fr[k * m - ((k * (k + 1)) >> 1) + lane] : 0.0;
   const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
-  const unsigned hmask = unsigned(__ballot(h2));
-  bool bad = false;
+  bool bad = (__ballot(h2) != 0ull);   // 1x1 pivots only (a second code path per pivot would double a fully unrolled body)
   int nneg = 0;
-  double myd0 = 0.0, myd1 = 0.0;     // lane j: D entries of pivot j
-  // 1x1 pivots only: a front with a hinted 2x2 pivot is left to the workgroup kernels (a second code path
-  // per pivot would double an already fully unrolled body -- instruction fetch, not arithmetic, is the limit)
-  if (hmask != 0u) bad = true;
+  double myd0 = 0.0;                   // lane j: inverse of pivot j
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
+  for (int j = 0; j < NC; ++j) {
     // no break / continue in here: the loop must unroll completely (static register indices)
     if (j < n) {
       const double d = readlane_f64(v[j], j);
@@ -696,13 +753,14 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
       if (lane > j && lane < m && !(fabs(own) <= inv_u)) bad = true;   // threshold test, whole column
       const double um = v[j];
 #pragma unroll
-      for (int k = j + 1; k < 32; ++k) {
+      for (int k = j + 1; k < NC; ++k) {
+        if (NC > 32 && k >= 32 && k >= n) continue;      // (uniform; the wide variant skips its idle tail)
         const double lkj = readlane_f64(um, k);
         v[k] = fma(-own, lkj, v[k]);
       }
       v[j] = (lane == j) ? 1.0 : own;
-      if (lane == j) { myd0 = rd; myd1 = 0.0; }
-      if (lane == 0) { ps[2 * j] = d; }
+      if (lane == j) myd0 = rd;
+      if (lane == 0) ps[j] = d;
     }
   }
   if (__ballot(bad) != 0ull) {
@@ -713,14 +771,14 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
     }
     return;
   }
-  // ---- factors out: column k of L (rows k..m-1), D, statistics ----------------------------------------
+  // ---- 3. factors out: column k of L (rows k..m-1), D, statistics -------------------------------------------
   if (Lf && t.lfoff >= 0) {
     // wave tier: straight into the two packed images the solves read (layout: "WAVE TIER" below); nothing
     // reads the rectangle of such a front again
     typedef double double2_t __attribute__((ext_vector_type(2)));
     double2_t* f = reinterpret_cast<double2_t*>(Lf + t.lfoff);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NC / 2; ++j) {
       const int r0 = 2 * j + 1;
       if (2 * j < n && lane >= r0 && lane < m) {
         double2_t e;
@@ -732,16 +790,17 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
     const int ri = lane >> 1, q = n >> 1;
     double* bk = Lbk + t.lboff + 2 * ((ri <= q) ? ri * ri : q * q + (ri - q) * n) + (lane & 1);
 #pragma unroll
-    for (int k = 0; k < 32; ++k)
+    for (int k = 0; k < NC; ++k)
       if (k < n && lane > k && lane < m) bk[2 * k] = v[k];
   } else {
+    double* Lb = L + t.loff;
 #pragma unroll
-    for (int k = 0; k < 32; ++k)
+    for (int k = 0; k < NC; ++k)
       if (k < n && lane >= k && lane < m) Lb[int64_t(k) * t.ld + lane] = v[k];
   }
   if (lane < n) {
     D[2 * int64_t(t.sptr + lane)] = myd0;
-    D[2 * int64_t(t.sptr + lane) + 1] = myd1;
+    D[2 * int64_t(t.sptr + lane) + 1] = 0.0;
   }
   if (lane == 0) {
     fastok[t.iblk] = 1;
@@ -750,18 +809,18 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
     if (nneg) atomicAdd(&stat[16 + (ti & (STAT_BINS - 1))], nneg);
   }
   if (!t.has_contrib || cm <= 0) return;
-  // ---- contribution block: C(i, j) -= sum_k (L D)(i, k) L(j, k) for the rows i >= j below the pivots -------
+  // ---- contribution block: C(i, j) = assembled(i, j) - sum_k (L D)(i, k) L(j, k), rows i >= j below the pivots ------
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  double ldv[32];
+  double ldv[NC];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) ldv[k] = (k < n) ? v[k] * ps[2 * k] : 0.0;
+  for (int k = 0; k < NC; ++k) ldv[k] = (k < n) ? v[k] * ps[k] : 0.0;
   double* Cb = C + t.coff;
-  for (int j0 = 0; j0 < cm; j0 += 8) {     // eight columns at a time: their loads of C are in flight together
-    double cold[8];                        // (one read-modify-write per column in turn cost a memory round trip each)
+  for (int j0 = 0; j0 < cm; j0 += 8) {
+    double cold[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int j = j0 + q;
-      cold[q] = (j < cm && lane >= n + j && lane < m) ? Cb[int64_t(j) * cm + (lane - n)] : 0.0;
+      const int j = j0 + q, c = n + j;
+      cold[q] = (j < cm && lane >= c && lane < m) ? Fr[c * m - ((c * (c + 1)) >> 1) + lane] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -769,7 +828,10 @@ k_front_tiny(const TinyFrontTask* __restrict__ tasks, int ntask, double* __restr
       if (j < cm) {                        // uniform
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) acc = fma(ldv[k], readlane_f64(v[k], n + j), acc);
+        for (int k = 0; k < NC; ++k) {
+          if (NC > 32 && k >= 32 && k >= n) continue;
+          acc = fma(ldv[k], readlane_f64(v[k], n + j), acc);
+        }
         cold[q] -= acc;
       }
     }
@@ -2817,8 +2879,8 @@ __global__ void k_gvar(int n, const int32_t* __restrict__ gperm, const int32_t* 
 }
 
 // rectangle -> the two packed images, for the wave-tier fronts that a workgroup kernel factorized (first
-// factorizations, blacklisted fronts, fronts of more than 32 columns); k_front_tiny writes the images itself.
-// mode 0: every task; mode 1: only those k_front_tiny did not do in this pass.  One wave per front.
+// factorizations, blacklisted fronts, fronts of more than TINY_N columns); k_front_wave writes the images itself.
+// mode 0: every task; mode 1: only those k_front_wave did not do in this pass.  One wave per front.
 __global__ void __launch_bounds__(256)
 k_wpack(const WTask* __restrict__ tasks, const WPack* __restrict__ packs, int ntask, int mode,
         const uint8_t* __restrict__ tinyskip, const double* __restrict__ L, double* __restrict__ Lf,
@@ -2829,7 +2891,7 @@ k_wpack(const WTask* __restrict__ tasks, const WPack* __restrict__ packs, int nt
   const WTask t = wave_task(tasks, ti);
   const WPack pk = packs[__builtin_amdgcn_readfirstlane(ti)];
   const int m = t.m, n = t.n;
-  if (mode == 1 && n <= 32 && !tinyskip[pk.node]) return;
+  if (mode == 1 && n <= TINY_N && !tinyskip[pk.node]) return;
   const int ld = (m + 1) & ~1;
   const double* A = L + pk.loff;
   double* f = Lf + t.lfoff;
@@ -2974,7 +3036,7 @@ void dev_free(DeviceFactor& F) {
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
-                  F.cztasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
+                  F.cztasks, F.pulljobs, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   // the caller's matrix (gsls_set_coo) depends on the pattern only, not on the elimination order: it survives
@@ -3029,7 +3091,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   // A -> L scatter lists with absolute destinations
   const int64_t nz = S.nptr[nn];
   std::vector<int64_t> asrc(nz), adst(nz);
-  std::vector<int32_t> arow(nz), acol(nz);
+  std::vector<int32_t> arow(nz), acol(nz), aloc(nz);
   for (int s = 0; s < nn; ++s) {
     const int64_t m = S.nrow(s);
     for (int64_t k = S.nptr[s]; k < S.nptr[s + 1]; ++k) {
@@ -3037,6 +3099,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       const int64_t c = dst / m, r = dst % m;
       asrc[k] = S.nlist[2 * k];
       adst[k] = S.loff[s] + c * S.ldl[s] + r;
+      aloc[k] = (m <= 64) ? int32_t(c * m - c * (c + 1) / 2 + r) : 0;     // k_front_wave's packed triangle in LDS
       arow[k] = S.rlist[S.rptr[s] + r];
       acol[k] = S.sptr[s] + int(c);
     }
@@ -3047,13 +3110,14 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<PullSeg> psg;
   std::vector<TinyContribTask> tct;
   std::vector<TinyFrontTask> tft;
+  std::vector<PullJob> pjobs;
   std::vector<PullTask> ptk;
   std::vector<int32_t> smalln, bign;
   std::vector<BigTrsv> btr;
   std::vector<BigGemv> bgm;
   int64_t part_max = 0;
   // one plan per node subset: everything (single device), my subtrees, the top part (multi-GPU)
-  // wg(s): the front is factorized by the workgroup kernels (else: by k_front_tiny, a wave per front)
+  // wg(s): the front is assembled and factorized by the workgroup kernels (else: by k_front_wave, a wave per front)
   auto build_plan = [&](std::vector<LevelPlan>& plan, auto keep, auto wg) {
   plan.assign(S.nlevels, LevelPlan());
   std::vector<int> lvl_nodes;
@@ -3094,7 +3158,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     lp.tinyc_begin = int(tct.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
       const int s = lvl_nodes[i];
-      if (!wg(s)) continue;              // k_front_tiny forms the contribution block itself
+      if (!wg(s)) continue;              // k_front_wave forms the contribution block itself
       if (S.sparent[s] >= nn) continue;  // roots have no (used) contribution block
       const int cm = S.nrow(s) - S.ncol(s);
       if (cm <= 16 && S.ncol(s) <= 64) {   // tiny: a wave per front (k_contrib_tiny)
@@ -3108,17 +3172,32 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     lp.tile_cnt = int(tt.size()) - lp.tile_begin;
     lp.tinyc_cnt = int(tct.size()) - lp.tinyc_begin;
     lp.tf_begin = int(tft.size());
-    for (int i = lp.node_begin; i < lp.node_end; ++i) {
-      const int s = lvl_nodes[i];
-      if (!wg(s))
-        tft.push_back(TinyFrontTask{S.ncol(s), S.nrow(s), S.ldl[s], S.sptr[s], S.loff[s], S.coff[s], nd[s].iblk,
-                                    (S.sparent[s] < nn) ? 1 : 0, s, 0, 0, 0});
+    for (int cls = 0; cls < TINY_CLASSES; ++cls) {        // by width class: each has its own unrolled kernel
+      lp.tf_cls_cnt[cls] = lp.tf_cls_maxm[cls] = 0;
+      for (int i = lp.node_begin; i < lp.node_end; ++i) {
+        const int s = lvl_nodes[i];
+        if (wg(s) || tiny_class(S.ncol(s)) != cls) continue;
+        TinyFrontTask tk{S.ncol(s), S.nrow(s), S.ldl[s], S.sptr[s], S.loff[s], S.coff[s], nd[s].iblk,
+                         (S.sparent[s] < nn) ? 1 : 0, s, 0, 0, 0, int64_t(pjobs.size()), S.nptr[s],
+                         int32_t(S.nptr[s + 1] - S.nptr[s]), 0};
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {      // children in clist order, 64 entries per job
+          const int c = S.clist[ci];
+          const int cmc = S.nrow(c) - S.ncol(c);
+          for (int e0 = 0; e0 < cmc * (cmc + 1) / 2; e0 += 64)
+            pjobs.push_back(PullJob{S.coff[c], S.cmapptr[c], cmc, e0});
+        }
+        tk.njob = int32_t(int64_t(pjobs.size()) - tk.job0);
+        tft.push_back(tk);
+        lp.tf_cls_maxm[cls] = std::max(lp.tf_cls_maxm[cls], S.nrow(s));
+        lp.tf_cls_cnt[cls]++;
+      }
     }
     lp.tf_cnt = int(tft.size()) - lp.tf_begin;
     // extend-add: one pull task per PCOLS columns of every parent, children in clist order
     lp.pull_begin = int(ptk.size());
     for (int i = lp.node_begin; i < lp.node_end; ++i) {
       const int s = lvl_nodes[i];
+      if (!wg(s)) continue;                     // k_front_wave assembles its front itself
       if (S.cptr[s + 1] == S.cptr[s]) continue;
       const int pm = S.nrow(s), pn = S.ncol(s);
       for (int pc0 = 0; pc0 < pm; pc0 += PCOLS) {
@@ -3189,8 +3268,22 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   };
   auto all = [](int) { return true; };
   build_plan(F.plan, all, all);
-  // the same schedule with the tiny fronts (n <= 32, m <= 64) handed to k_front_tiny (LDL^T refactorizations)
-  build_plan(F.planT, all, [&](int s) { return !(S.ncol(s) <= 32 && S.nrow(s) <= 64); });
+  // the same schedule with the tiny fronts (n <= TINY_N, m <= 64) handed to k_front_wave (LDL^T refactorizations)
+  auto is_wg = [&](int s) { return !(S.ncol(s) <= TINY_N && S.nrow(s) <= 64); };
+  build_plan(F.planT, all, is_wg);
+  {
+    // A -> L scatter of that schedule: only the fronts the workgroup kernels assemble
+    std::vector<int64_t> s2, d2;
+    for (int s = 0; s < nn; ++s)
+      if (is_wg(s))
+        for (int64_t k = S.nptr[s]; k < S.nptr[s + 1]; ++k) {
+          s2.push_back(asrc[k]);
+          d2.push_back(adst[k]);
+        }
+    F.nscatter_wg = int64_t(s2.size());
+    HIPCHK(upload(F.asrc_wg, s2, st));
+    HIPCHK(upload(F.adst_wg, d2, st));
+  }
   F.sharded = !S.owner.empty() && S.nranks > 1;
   if (F.sharded) {
     build_plan(F.planA, [&](int s) { return S.owner[s] == F.myrank; }, all);
@@ -3531,7 +3624,11 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     TinyFrontTask* d4 = nullptr;
     HIPCHK(upload(d4, tft, st));
     F.tftasks = d4;
+    PullJob* d5 = nullptr;
+    HIPCHK(upload(d5, pjobs, st));
+    F.pulljobs = d5;
   }
+  HIPCHK(upload(F.aloc, aloc, st));
   HIPCHK(upload(F.asrc, asrc, st));
   HIPCHK(upload(F.adst, adst, st));
   HIPCHK(upload(F.arow, arow, st));
@@ -3547,7 +3644,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     std::vector<ZeroTask> zt;
     F.cz_begin.assign(S.nlevels, 0);
     F.cz_cnt.assign(S.nlevels, 0);
-    const int64_t chunk = int64_t(1) << 16;        // 512 KB per workgroup
+    const int64_t chunk = int64_t(1) << 13;        // 64 KB per workgroup
     for (int l = 0; l < S.nlevels; ++l) {
       F.cz_begin[l] = int(zt.size());
       for (int r = S.czptr[l]; r < S.czptr[l + 1]; ++r)
@@ -3602,11 +3699,40 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
     if (!POSDEF && !F.tpp_cnt[which].empty() && F.tpp_cnt[which][l] > 0)   // fronts flagged for whole-front pivoting
       hipLaunchKernelGGL(k_front_tpp, dim3(F.tpp_cnt[which][l]), dim3(256), 0, st, F.nodes,
                          F.tpplist + F.tpp_begin[which][l], F.L, F.D, F.gperm, F.stat, F.faillist, small, u, S.nnodes);
-    if (!POSDEF && lp.tf_cnt > 0)   // only in the tiny-front plan (planT)
-      hipLaunchKernelGGL(k_front_tiny, dim3((lp.tf_cnt + 3) / 4), dim3(256), 0, st,
-                         static_cast<const TinyFrontTask*>(F.tftasks) + lp.tf_begin, lp.tf_cnt, F.L, F.D, F.C,
-                         F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr,
-                         F.wave ? F.Lb : nullptr);
+    if (!POSDEF && lp.tf_cnt > 0) {   // only in the tiny-front plan (planT): assembly + factorization, a wave per front
+      const PullJob* pj = static_cast<const PullJob*>(F.pulljobs);
+      // one launch per width class on a wide level; on a narrow one (latency, not throughput) a single launch of
+      // the widest class present.  Classes with few fronts ride with the next wider one.
+      int beg = lp.tf_begin, cnt = 0, maxm = 0;
+      const bool narrow = lp.tf_cnt <= 2048;
+      for (int cls = 0; cls < TINY_CLASSES; ++cls) {
+        cnt += lp.tf_cls_cnt[cls];
+        maxm = std::max(maxm, lp.tf_cls_maxm[cls]);
+        int later = 0;
+        for (int c2 = cls + 1; c2 < TINY_CLASSES; ++c2) later += lp.tf_cls_cnt[c2];
+        if (cnt == 0 || (later > 0 && (narrow || cnt < 512))) continue;
+        const TinyFrontTask* tf = static_cast<const TinyFrontTask*>(F.tftasks) + beg;
+        const int tri = (maxm * (maxm + 1) / 2 + 1) & ~1;
+#define GSLS_FW_ARGS tf, cnt, pj, F.cmap, F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, \
+                     F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri
+        switch (cls) {
+          case 0:
+            hipLaunchKernelGGL((k_front_wave<24, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
+            break;
+          case 1:
+            hipLaunchKernelGGL((k_front_wave<28, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
+            break;
+          case 2:
+            hipLaunchKernelGGL((k_front_wave<32, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
+            break;
+          default:
+            hipLaunchKernelGGL((k_front_wave<TINY_N, 2>), dim3((cnt + 1) / 2), dim3(128), size_t(2) * tri * 8, st, GSLS_FW_ARGS);
+        }
+#undef GSLS_FW_ARGS
+        beg += cnt;
+        cnt = maxm = 0;
+      }
+    }
     const int nsteps = int(lp.panel_cnt.size() / 2);
     for (int s = 0; s < nsteps; ++s) {
       if (lp.panel_cnt[2 * s] > 0) {
@@ -3644,6 +3770,10 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
     if (!POSDEF && &plan == &F.planT && l < int(F.bl_level.size()) && F.bl_level[l].np > 0) {
       // tiny fronts that k_front_tiny could not take (blacklisted by the host): the workgroup kernels
       const BlLevel& b = F.bl_level[l];
+      if (b.npull > 0)
+        hipLaunchKernelGGL(k_assemble_pull, dim3(b.npull), dim3(256), 0, st,
+                           static_cast<const PullTask*>(F.bl_pulltasks) + b.pullbeg,
+                           static_cast<const PullSeg*>(F.bl_pullsegs), F.cmap, F.L, F.C);
       const int nrt = std::max(NB / 16, (b.rows + 15) / 16);
       const int ldq = (16 * nrt) % 32 == 16 ? 16 * nrt : 16 * nrt + 16;
       const size_t lds_fldl = sizeof(double) * ldq * (NB + 16);
@@ -3683,12 +3813,33 @@ hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std:
   std::vector<PanelTask> pt;
   std::vector<TileTask> tt;
   std::vector<TinyContribTask> tc;
+  std::vector<PullSeg> psg;
+  std::vector<PullTask> ptk;
   F.bl_level.assign(S.nlevels, BlLevel());
   for (int l = 0; l < S.nlevels; ++l) {
     BlLevel& b = F.bl_level[l];
     b.pbeg = int(pt.size());
     b.tbeg = int(tt.size());
     b.tcbeg = int(tc.size());
+    b.pullbeg = int(ptk.size());
+    for (int s : per[l]) {                   // the extend-add k_front_wave would have done itself
+      const int pm = S.nrow(s), pn = S.ncol(s);
+      for (int pc0 = 0; pc0 < pm; pc0 += PCOLS) {
+        PullTask tk{int(psg.size()), 0};
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
+          const int c = S.clist[ci];
+          const int cmc = S.nrow(c) - S.ncol(c);
+          const int32_t* mp = S.cmap.data() + S.cmapptr[c];
+          const int j0 = int(std::lower_bound(mp, mp + cmc, pc0) - mp);
+          const int j1 = int(std::lower_bound(mp, mp + cmc, pc0 + PCOLS) - mp);
+          if (j1 > j0)
+            psg.push_back(PullSeg{j0, j1, cmc, pn, S.ldl[s], pm - pn, S.cmapptr[c], S.coff[c], S.loff[s], S.coff[s]});
+        }
+        tk.seg_cnt = int(psg.size()) - tk.seg_begin;
+        if (tk.seg_cnt > 0) ptk.push_back(tk);
+      }
+    }
+    b.npull = int(ptk.size()) - b.pullbeg;
     for (int s : per[l]) {
       pt.push_back(PanelTask{s, 0, 0, 0});
       b.rows = std::max(b.rows, std::min(PR, S.nrow(s)));
@@ -3702,11 +3853,22 @@ hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std:
     b.nt = int(tt.size()) - b.tbeg;
     b.ntc = int(tc.size()) - b.tcbeg;
   }
-  for (void* p2 : {static_cast<void*>(F.bl_ptasks), static_cast<void*>(F.bl_ttasks), F.bl_tctasks})
+  for (void* p2 : {static_cast<void*>(F.bl_ptasks), static_cast<void*>(F.bl_ttasks), F.bl_tctasks, F.bl_pullsegs,
+                   F.bl_pulltasks})
     if (p2) (void)hipFree(p2);
   F.bl_ptasks = nullptr;
   F.bl_ttasks = nullptr;
   F.bl_tctasks = nullptr;
+  F.bl_pullsegs = F.bl_pulltasks = nullptr;
+  F.bl_count = int(nodes.size());
+  {
+    PullSeg* d1 = nullptr;
+    PullTask* d2 = nullptr;
+    HIPCHK(upload(d1, psg, st));
+    HIPCHK(upload(d2, ptk, st));
+    F.bl_pullsegs = d1;
+    F.bl_pulltasks = d2;
+  }
   HIPCHK(upload(F.bl_ptasks, pt, st));
   HIPCHK(upload(F.bl_ttasks, tt, st));
   {
@@ -3879,15 +4041,21 @@ static hipError_t ensure_linv(DeviceFactor& F) {
 
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,
                       const double* d_scale, double small, double u, hipStream_t st, bool use_tiny) {
-  HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
+  // with the wave-per-front plan only the fronts of the workgroup kernels take their entries of A through the
+  // rectangle in HBM (k_front_wave gathers its own); blacklisted fronts are workgroup fronts again: full scatter
+  const bool part = use_tiny && F.bl_count == 0;
+  F.cur_val = d_val;
+  if (!part || F.nscatter_wg > 0)
+    HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
   HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
   static const std::vector<int32_t> init = [] { std::vector<int32_t> v(NSTAT, 0); v[0] = INT_MAX; return v; }();
   HIPCHK(hipMemcpyAsync(F.stat, init.data(), NSTAT * sizeof(int32_t), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_iota, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm);
-  if (F.nscatter > 0) {
-    const int blocks = int(std::min<int64_t>((F.nscatter + 255) / 256, 256 * 8));
-    hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, F.nscatter, F.asrc, F.adst, d_val,
-                       F.L, d_scale, F.arow, F.acol, F.invp);
+  const int64_t nsc = part ? F.nscatter_wg : F.nscatter;
+  if (nsc > 0) {
+    const int blocks = int(std::min<int64_t>((nsc + 255) / 256, 256 * 8));
+    hipLaunchKernelGGL(k_scatter_a, dim3(blocks), dim3(256), 0, st, nsc, part ? F.asrc_wg : F.asrc,
+                       part ? F.adst_wg : F.adst, d_val, F.L, d_scale, F.arow, F.acol, F.invp);
   }
   if (posdef) {
     HIPCHK(ensure_linv(F));

@@ -48,7 +48,9 @@ struct LevelPlan {
   std::vector<int> panel_begin, panel_cnt;  // per step: range in the PanelTask array
   int tile_begin, tile_cnt;                 // range in the TileTask array
   int tinyc_begin, tinyc_cnt;               // fronts with a tiny contribution block (k_contrib_tiny)
-  int tf_begin = 0, tf_cnt = 0;             // whole tiny fronts (k_front_tiny), only in planT
+  int tf_begin = 0, tf_cnt = 0;             // whole tiny fronts (k_front_wave), only in planT
+  int tf_cls_cnt[4] = {0, 0, 0, 0};         // ... by width class (24 / 28 / 32 / 48 columns), in that order
+  int tf_cls_maxm[4] = {0, 0, 0, 0};        // tallest front of each class (sizes the LDS triangle)
   int pull_begin, pull_cnt;                 // extend-add tasks of the level (k_assemble_pull)
   int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
   int tiny32_cnt = 0;                       // ... of which the first tiny32_cnt have n <= 32
@@ -59,7 +61,7 @@ struct LevelPlan {
 
 // per level: tiny fronts blacklisted from k_front_tiny (ranges in bl_ptasks / bl_ttasks / bl_tctasks)
 struct BlLevel {
-  int pbeg = 0, np = 0, tbeg = 0, nt = 0, tcbeg = 0, ntc = 0, rows = 0;
+  int pbeg = 0, np = 0, tbeg = 0, nt = 0, tcbeg = 0, ntc = 0, rows = 0, pullbeg = 0, npull = 0;
 };
 
 struct DeviceFactor {
@@ -81,6 +83,15 @@ struct DeviceFactor {
   PanelTask* bl_ptasks = nullptr;
   TileTask* bl_ttasks = nullptr;
   void* bl_tctasks = nullptr;
+  void* bl_pullsegs = nullptr;     // extend-add of the blacklisted fronts (k_front_wave assembles the others itself)
+  void* bl_pulltasks = nullptr;
+  int bl_count = 0;
+  void* pulljobs = nullptr;        // k_front_wave: one job per column of every child's contribution block
+  int32_t* aloc = nullptr;         // ... and the position of every entry of A in its front's LDS triangle
+  int64_t* asrc_wg = nullptr;      // A -> L scatter restricted to the workgroup fronts of planT
+  int64_t* adst_wg = nullptr;
+  int64_t nscatter_wg = 0;
+  const double* cur_val = nullptr; // the values of the factorization in flight
   std::vector<BlLevel> bl_level;
   int32_t* smallnodes = nullptr;
   void* stasks = nullptr;          // SolveTask per entry of smallnodes (same indexing)

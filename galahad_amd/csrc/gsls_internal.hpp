@@ -72,6 +72,7 @@ void shard_tree(Symbolic& S, int nranks);
 // offsets of the contribution blocks: reuse = true packs them by lifetime (single device), false lays them out one
 // after the other (multi-GPU: the cut roots' blocks must survive until the exchange)
 void layout_contrib(Symbolic& S, bool reuse);
+void layout_contrib_auto(Symbolic& S);       // reuse when the blocks would not fit side by side comfortably
 
 inline int align_ld(int m) { return (m + 1) & ~1; }   // 16-byte aligned columns
 

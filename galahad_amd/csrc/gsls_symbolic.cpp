@@ -455,7 +455,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
     S.ldl[s] = align_ld(int(m));
     S.loff[s + 1] = S.loff[s] + int64_t(S.ldl[s]) * ne;
   }
-  layout_contrib(S, true);
+  layout_contrib_auto(S);
   return flag;
 }
 
@@ -464,6 +464,13 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
 // time: levels run in order, a block is allocated when its front's level starts and released once its parent's level
 // has pulled it, first fit.  Without that the arena is the sum over ALL fronts -- hundreds of GB for a 3-D problem whose
 // factor itself is 30 GB.
+void layout_contrib_auto(Symbolic& S) {
+  // small trees: one block per front and one clear per factorization (no per-level clears on the launch path)
+  int64_t total = 0;
+  for (int s = 0; s < S.nnodes; ++s) total += int64_t(S.nrow(s) - S.ncol(s)) * (S.nrow(s) - S.ncol(s));
+  layout_contrib(S, total > (int64_t(1) << 27));      // reuse above 1 GiB
+}
+
 void layout_contrib(Symbolic& S, bool reuse) {
   const int nn = S.nnodes;
   S.coff.assign(nn + 1, 0);
@@ -554,7 +561,8 @@ void shard_tree(Symbolic& S, int nranks) {
   S.nranks = std::max(1, nranks);
   S.owner.assign(nn, 0);
   S.cutroots.clear();
-  layout_contrib(S, S.nranks <= 1);      // the cut roots' blocks outlive their level: no reuse across ranks
+  if (S.nranks > 1) layout_contrib(S, false);      // the cut roots' blocks outlive their level: no reuse across ranks
+  else layout_contrib_auto(S);
   if (S.nranks <= 1 || nn == 0) return;
   std::vector<double> w(nn, 0.0), W(nn, 0.0);
   for (int s = 0; s < nn; ++s) {

@@ -23,6 +23,8 @@ def problem(case):
         return P.grid3d(14, 13, 12), True
     if case == "grid3d_ldlt":              # SPD matrix through the pivoted LDL^T kernels
         return P.grid3d(12, 11, 10), False
+    if case == "cfg5_ldlt":                # BASELINE.json configs[4] pattern (27-point + long-range edges), reduced grid
+        return P.grid3d_27pt_perturbed(36, 36, 36), False
     if case == "random_indef":             # mixed-sign diagonal, 2x2 pivots and a few delays
         return P.random_sparse(4000, 6, seed=11, spd=False), False
     if case in ("kkt_indef", "kkt_refined"):   # saddle point: delayed pivots -> sharded order repair, unless the

@@ -174,6 +174,8 @@ def test_not_positive_definite_and_singular_status():
     ("grid3d_16", lambda: P.grid3d(16, 16, 16), True),
     ("kkt_6000_1200", lambda: P.kkt_qpband(6000, 1200), False),
     ("rand_spd_5000", lambda: P.random_sparse(5000, 4, 21, spd=True), True),
+    ("grid3d_27pt_cfg5_16_chol", lambda: P.grid3d_27pt_perturbed(16, 16, 16), True),
+    ("grid3d_27pt_cfg5_16_ldlt", lambda: P.grid3d_27pt_perturbed(16, 16, 16), False),
 ])
 def test_against_c_oracle(name, prob, posdef):
     """same seeded input through the HIP path and through oracle/gsls_oracle.c, same PERM."""

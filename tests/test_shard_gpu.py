@@ -43,7 +43,7 @@ def launch(case, world, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,world", [("grid2d_spd", 2), ("banded_spd", 2), ("grid3d_spd", 3),
-                                        ("grid3d_ldlt", 2), ("kkt_refined", 2)])
+                                        ("grid3d_ldlt", 2), ("kkt_refined", 2), ("cfg5_ldlt", 2)])
 def test_tree_sharded_matches_single_device(case, world, tmp_path):
     res = launch(case, world, tmp_path)
     for r in res:
