@@ -33,7 +33,9 @@ __device__ unsigned long long g_stamps[64];
 #define STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PH(k) do { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); phacc[k] += t__ - pht; pht = t__; } while (0)
 #define STAMPN(i) do { __syncthreads(); if (threadIdx.x == 0 && nd.m > 300 && nd.n > 100 && nd.m > nd.n) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPW(i) do { if (lane == 0 && !t.has_contrib) g_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define STAMPW(i) do {} while (0)
 #define STAMP(i) do {} while (0)
 #define PH(k) do {} while (0)
 #define STAMPN(i) do {} while (0)
@@ -655,25 +657,75 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 // workgroup kernels need five.  Any failed test only raises stat[13]; the host then repeats the factorization with
 // that front on the workgroup path (which has the pivoting fallbacks).  A front with a hinted 2x2 pivot fails at once.
 // =================================================================================================
-constexpr int TINY_N = 48;
-constexpr int TINY_CLASSES = 4;                     // unrolled for 24, 28, 32 and 48 columns
-static inline int tiny_class(int n) { return n <= 24 ? 0 : n <= 28 ? 1 : n <= 32 ? 2 : 3; }
+constexpr int TINY_N = 64;
+constexpr int TINY_CLASSES = 5;                     // unrolled for 24, 28, 32 and 48 columns; up to 64: k_front_lds
+static inline int tiny_class(int n) { return n <= 24 ? 0 : n <= 28 ? 1 : n <= 32 ? 2 : n <= 48 ? 3 : 4; }
 struct TinyFrontTask {
   int32_t n, m, ld, sptr;
   int64_t loff, coff;
-  int32_t iblk, has_contrib, node, njob;
+  int32_t iblk, has_contrib, node, nd;   // nd: entries of the front that children add to
   int64_t lfoff, lboff;      // wave tier: the front's packed images (written instead of the rectangle)
-  int64_t job0, a0;          // its PullJob range, its range of A entries (asrc / aloc)
+  int64_t d0, s0, a0;        // its ranges in the gather lists (gdst/gbeg, gsrc) and in A's entry lists (asrc/aloc)
   int32_t acnt, pad;
 };
-struct PullJob {             // up to 64 entries of one child's contribution block (lower triangle, row by row)
-  int64_t coff, mapoff;      // the child's block in the arena, its row map (cmap)
-  int32_t cm, e0;            // its order; first entry of this job: e = i (i + 1) / 2 + j, j <= i
+// Extend-add as a GATHER: for every entry of the front that receives something, the arena offsets of the children's
+// entries that land there, children in clist order (the order the scatter form k_assemble_pull adds them in).
+//   gdst[k] = LDS offset of the entry (low 12 bits) | number of sources << 12;  gbeg[k] = first source, relative to s0
+struct GatherLists {
+  const uint32_t* gdst;
+  const int32_t* gbeg;
+  const int64_t* gsrc;
 };
+// step 1 of both wave-per-front kernels: the assembled front (lower triangle, packed columns) in LDS
+__device__ __forceinline__ void front_assemble(const TinyFrontTask& t, double* Fr, int lane, const GatherLists g,
+                                               const int64_t* __restrict__ asrc, const int32_t* __restrict__ aloc,
+                                               const double* __restrict__ val, const double* __restrict__ C) {
+  const int m = t.m;
+  // (the loads of A's entries are issued before the triangle is zeroed)
+  double av[2];
+  int al[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = lane + 64 * q;
+    const bool ok = e < t.acnt;
+    al[q] = ok ? aloc[t.a0 + e] : -1;
+    av[q] = ok ? val[asrc[t.a0 + (ok ? e : 0)]] : 0.0;
+  }
+  const int tot = (m * (m + 1)) >> 1;
+  for (int e = lane; e < tot; e += 64) Fr[e] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (al[q] >= 0) Fr[al[q]] = av[q];
+  for (int e = lane + 128; e < t.acnt; e += 64) Fr[aloc[t.a0 + e]] = val[asrc[t.a0 + e]];
+  STAMPW(56);
+  // the children: a lane per receiving entry, its sources eight at a time (their offsets fetched one round ahead)
+  for (int k0 = 0; k0 < t.nd; k0 += 64) {
+    const bool ok = k0 + lane < t.nd;
+    const int64_t k = t.d0 + (ok ? k0 + lane : t.nd - 1);
+    const uint32_t dd = g.gdst[k];
+    const int64_t* sp = g.gsrc + t.s0 + g.gbeg[k];
+    const int dst = int(dd & 4095u), cnt = ok ? int(dd >> 12) : 0;
+    int64_t idx[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) idx[q] = sp[min(q, max(cnt - 1, 0))];
+    double acc = ok ? Fr[dst] : 0.0;
+    for (int p = 0; __any(p < cnt); p += 8) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = C[idx[q]];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) idx[q] = sp[min(p + 8 + q, max(cnt - 1, 0))];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += (p + q < cnt) ? v[q] : 0.0;
+    }
+    if (ok) Fr[dst] = acc;
+  }
+}
+
 template <int NC, int WPB>
 __global__ void __launch_bounds__(64 * WPB)
-k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const PullJob* __restrict__ jobs,
-             const int32_t* __restrict__ cmap, const int64_t* __restrict__ asrc, const int32_t* __restrict__ aloc,
+k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLists g,
+             const int64_t* __restrict__ asrc, const int32_t* __restrict__ aloc,
              const double* __restrict__ val, double* __restrict__ L, double* __restrict__ D, double* __restrict__ C,
              int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
              const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u,
@@ -688,47 +740,9 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const PullJob* 
   const int n = t.n, m = t.m, cm = m - n;
   double* Fr = fsh + wave * tri;     // column c (rows c..m-1) at Fr[c*m - c(c+1)/2 + r]
   double* ps = psh[wave];
-  // ---- 1. the assembled front in LDS ----------------------------------------------------------------
-  {
-    // (the loads of A's entries and of the first children are issued before the triangle is zeroed)
-    double av[2];
-    int al[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = lane + 64 * q;
-      const bool ok = e < t.acnt;
-      al[q] = ok ? aloc[t.a0 + e] : -1;
-      av[q] = ok ? val[asrc[t.a0 + (ok ? e : 0)]] : 0.0;
-    }
-    const int tot = (m * (m + 1)) >> 1;
-    for (int e = lane; e < tot; e += 64) Fr[e] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (al[q] >= 0) Fr[al[q]] = av[q];
-    for (int e = lane + 128; e < t.acnt; e += 64) Fr[aloc[t.a0 + e]] = val[asrc[t.a0 + e]];
-    for (int j0 = 0; j0 < t.njob; j0 += 8) {
-      double cv[8];
-      int cd[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const bool on = j0 + q < t.njob;                 // uniform
-        const PullJob jb = jobs[t.job0 + (on ? j0 + q : j0)];
-        const int e = jb.e0 + lane;
-        int i = int((sqrtf(float(8 * e + 1)) - 1.0f) * 0.5f);
-        if (((i + 1) * (i + 2)) >> 1 <= e) ++i;
-        if ((i * (i + 1)) >> 1 > e) --i;
-        const int j = e - ((i * (i + 1)) >> 1);
-        const bool ok = on && i < jb.cm;
-        cv[q] = ok ? C[jb.coff + int64_t(j) * jb.cm + i] : 0.0;
-        const int pr = ok ? cmap[jb.mapoff + i] : 0;
-        const int pc = ok ? cmap[jb.mapoff + j] : 0;
-        cd[q] = ok ? pc * m - ((pc * (pc + 1)) >> 1) + pr : -1;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q)          // one child after the other: the sums do not depend on the batching
-        if (cd[q] >= 0) Fr[cd[q]] += cv[q];
-    }
-  }
+  STAMPW(49);
+  front_assemble(t, Fr, lane, g, asrc, aloc, val, C);
+  STAMPW(50);
   const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
   // ---- 2. rows into registers, the pivots ----------------------------------------------------------------
   double v[NC];
@@ -763,6 +777,7 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const PullJob* 
       if (lane == 0) ps[j] = d;
     }
   }
+  STAMPW(51);
   if (__ballot(bad) != 0ull) {
     if (lane == 0) {
       const int slot = atomicAdd(&stat[13], 1);
@@ -808,6 +823,7 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const PullJob* 
     atomicAdd(&stat[16 + STAT_BINS + (ti & (STAT_BINS - 1))], 1);
     if (nneg) atomicAdd(&stat[16 + (ti & (STAT_BINS - 1))], nneg);
   }
+  STAMPW(52);
   if (!t.has_contrib || cm <= 0) return;
   // ---- contribution block: C(i, j) = assembled(i, j) - sum_k (L D)(i, k) L(j, k), rows i >= j below the pivots ------
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -2906,6 +2922,106 @@ k_wpack(const WTask* __restrict__ tasks, const WPack* __restrict__ packs, int nt
   }
 }
 
+// The same front kernel with the matrix left in LDS and every loop rolled: ~2 KB of code instead of 28-80 KB.  On a
+// level with a handful of fronts the unrolled kernels spend their time fetching instructions (one cold pass through
+// the whole body per launch); this one is for those levels, and for fronts of 49..64 columns on any level.
+template <int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+k_front_lds(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLists g,
+            const int64_t* __restrict__ asrc, const int32_t* __restrict__ aloc,
+            const double* __restrict__ val, double* __restrict__ L, double* __restrict__ D, double* __restrict__ C,
+            int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
+            const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u,
+            double* __restrict__ Lf, double* __restrict__ Lbk, int tri) {
+  extern __shared__ __attribute__((aligned(16))) double fsh[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (ti >= ntask) return;
+  const TinyFrontTask t = tasks[ti];
+  if (tinyskip[t.node]) return;
+  const int n = t.n, m = t.m, cm = m - n;
+  double* Fr = fsh + wave * tri;
+  front_assemble(t, Fr, lane, g, asrc, aloc, val, C);
+  const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
+  const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
+  bool bad = (__ballot(h2) != 0ull);
+  int nneg = 0;
+  double myd0 = 0.0;
+  const bool in = lane < m;
+  for (int j = 0; j < n; ++j) {
+    const int oj = j * m - ((j * (j + 1)) >> 1);
+    const double cj = (in && lane >= j) ? Fr[oj + lane] : 0.0;
+    const double d = readlane_f64(cj, j);
+    if (!(fabs(d) >= small)) bad = true;
+    if (d < 0.0) ++nneg;
+    double rd = __builtin_amdgcn_rcp(d);
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
+    const double own = cj * rd;
+    if (in && lane > j && !(fabs(own) <= inv_u)) bad = true;
+    int k = j + 1;
+    for (; k + 3 < m; k += 4) {          // four columns' reads in flight, then their writes
+      double f[4], l[4];
+      int o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = k + q;
+        o[q] = kk * m - ((kk * (kk + 1)) >> 1) + lane;
+        l[q] = readlane_f64(cj, kk);
+        f[q] = (in && lane >= kk) ? Fr[o[q]] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (in && lane >= k + q) Fr[o[q]] = fma(-own, l[q], f[q]);
+    }
+    for (; k < m; ++k) {
+      const int o = k * m - ((k * (k + 1)) >> 1) + lane;
+      const double l = readlane_f64(cj, k);
+      if (in && lane >= k) Fr[o] = fma(-own, l, Fr[o]);
+    }
+    if (in && lane > j) Fr[oj + lane] = own;
+    if (lane == j) myd0 = rd;
+  }
+  if (__ballot(bad) != 0ull) {
+    if (lane == 0) {
+      const int slot = atomicAdd(&stat[13], 1);
+      if (slot < FAILCAP) tinyfail[slot] = t.node;
+      fastok[t.iblk] = 0;
+    }
+    return;
+  }
+  if (Lf && t.lfoff >= 0) {
+    double* f = Lf + t.lfoff;
+    double* bk = Lbk + t.lboff;
+    for (int k = 0; k < n; ++k)
+      if (in && lane > k) {
+        const double v = Fr[k * m - ((k * (k + 1)) >> 1) + lane];
+        const int j = k >> 1;
+        f[2 * (wf_pair_off(j, m) + lane - (2 * j + 1)) + (k & 1)] = v;
+        bk[2 * (wb_pair_off(lane >> 1, n) + k) + (lane & 1)] = v;
+      }
+  } else {
+    double* Lb = L + t.loff;
+    for (int k = 0; k < n; ++k)
+      if (in && lane >= k) Lb[int64_t(k) * t.ld + lane] = (lane == k) ? 1.0 : Fr[k * m - ((k * (k + 1)) >> 1) + lane];
+  }
+  if (lane < n) {
+    D[2 * int64_t(t.sptr + lane)] = myd0;
+    D[2 * int64_t(t.sptr + lane) + 1] = 0.0;
+  }
+  if (lane == 0) {
+    fastok[t.iblk] = 1;
+    atomicAdd(&stat[16 + STAT_BINS + (ti & (STAT_BINS - 1))], 1);
+    if (nneg) atomicAdd(&stat[16 + (ti & (STAT_BINS - 1))], nneg);
+  }
+  if (!t.has_contrib || cm <= 0) return;
+  double* Cb = C + t.coff;
+  for (int j = 0; j < cm; ++j) {
+    const int c = n + j;
+    if (in && lane >= c) Cb[int64_t(j) * cm + (lane - n)] = Fr[c * m - ((c * (c + 1)) >> 1) + lane];
+  }
+}
+
 // D solve restricted to the pivots of the fronts in `list` (one workgroup each): the fronts the wave tier does not
 // cover, when it applies D to its own fronts inside the forward step
 __global__ void __launch_bounds__(256)
@@ -3036,7 +3152,7 @@ void dev_free(DeviceFactor& F) {
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
-                  F.cztasks, F.pulljobs, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
+                  F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   // the caller's matrix (gsls_set_coo) depends on the pattern only, not on the elimination order: it survives
@@ -3110,7 +3226,10 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<PullSeg> psg;
   std::vector<TinyContribTask> tct;
   std::vector<TinyFrontTask> tft;
-  std::vector<PullJob> pjobs;
+  std::vector<uint32_t> gdst;
+  std::vector<int32_t> gbeg;
+  std::vector<int64_t> gsrc;
+  std::vector<std::pair<int32_t, int64_t>> gtmp;
   std::vector<PullTask> ptk;
   std::vector<int32_t> smalln, bign;
   std::vector<BigTrsv> btr;
@@ -3178,15 +3297,29 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         const int s = lvl_nodes[i];
         if (wg(s) || tiny_class(S.ncol(s)) != cls) continue;
         TinyFrontTask tk{S.ncol(s), S.nrow(s), S.ldl[s], S.sptr[s], S.loff[s], S.coff[s], nd[s].iblk,
-                         (S.sparent[s] < nn) ? 1 : 0, s, 0, 0, 0, int64_t(pjobs.size()), S.nptr[s],
-                         int32_t(S.nptr[s + 1] - S.nptr[s]), 0};
-        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {      // children in clist order, 64 entries per job
+                         (S.sparent[s] < nn) ? 1 : 0, s, 0, 0, 0, int64_t(gdst.size()), int64_t(gsrc.size()),
+                         S.nptr[s], int32_t(S.nptr[s + 1] - S.nptr[s]), 0};
+        gtmp.clear();
+        const int pm = S.nrow(s);
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {      // children in clist order
           const int c = S.clist[ci];
           const int cmc = S.nrow(c) - S.ncol(c);
-          for (int e0 = 0; e0 < cmc * (cmc + 1) / 2; e0 += 64)
-            pjobs.push_back(PullJob{S.coff[c], S.cmapptr[c], cmc, e0});
+          const int32_t* mp = S.cmap.data() + S.cmapptr[c];
+          for (int j = 0; j < cmc; ++j)
+            for (int i = j; i < cmc; ++i)
+              gtmp.emplace_back(mp[j] * pm - mp[j] * (mp[j] + 1) / 2 + mp[i], S.coff[c] + int64_t(j) * cmc + i);
         }
-        tk.njob = int32_t(int64_t(pjobs.size()) - tk.job0);
+        std::stable_sort(gtmp.begin(), gtmp.end(),
+                         [](const std::pair<int32_t, int64_t>& x, const std::pair<int32_t, int64_t>& y) { return x.first < y.first; });
+        for (size_t e = 0; e < gtmp.size();) {
+          size_t e2 = e;
+          while (e2 < gtmp.size() && gtmp[e2].first == gtmp[e].first) ++e2;
+          gdst.push_back(uint32_t(gtmp[e].first) | (uint32_t(e2 - e) << 12));
+          gbeg.push_back(int32_t(int64_t(gsrc.size()) - tk.s0));
+          for (size_t q = e; q < e2; ++q) gsrc.push_back(gtmp[q].second);
+          e = e2;
+        }
+        tk.nd = int32_t(int64_t(gdst.size()) - tk.d0);
         tft.push_back(tk);
         lp.tf_cls_maxm[cls] = std::max(lp.tf_cls_maxm[cls], S.nrow(s));
         lp.tf_cls_cnt[cls]++;
@@ -3624,9 +3757,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     TinyFrontTask* d4 = nullptr;
     HIPCHK(upload(d4, tft, st));
     F.tftasks = d4;
-    PullJob* d5 = nullptr;
-    HIPCHK(upload(d5, pjobs, st));
-    F.pulljobs = d5;
+    HIPCHK(upload(F.gdst, gdst, st));
+    HIPCHK(upload(F.gbeg, gbeg, st));
+    HIPCHK(upload(F.gsrc, gsrc, st));
   }
   HIPCHK(upload(F.aloc, aloc, st));
   HIPCHK(upload(F.asrc, asrc, st));
@@ -3700,11 +3833,12 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
       hipLaunchKernelGGL(k_front_tpp, dim3(F.tpp_cnt[which][l]), dim3(256), 0, st, F.nodes,
                          F.tpplist + F.tpp_begin[which][l], F.L, F.D, F.gperm, F.stat, F.faillist, small, u, S.nnodes);
     if (!POSDEF && lp.tf_cnt > 0) {   // only in the tiny-front plan (planT): assembly + factorization, a wave per front
-      const PullJob* pj = static_cast<const PullJob*>(F.pulljobs);
+      const GatherLists gl{F.gdst, F.gbeg, F.gsrc};
       // one launch per width class on a wide level; on a narrow one (latency, not throughput) a single launch of
       // the widest class present.  Classes with few fronts ride with the next wider one.
       int beg = lp.tf_begin, cnt = 0, maxm = 0;
-      const bool narrow = lp.tf_cnt <= 2048;
+      static const int narrow_max = getenv("GSLS_NARROW_MAX") ? atoi(getenv("GSLS_NARROW_MAX")) : 2048;
+      const bool narrow = lp.tf_cnt <= narrow_max;
       for (int cls = 0; cls < TINY_CLASSES; ++cls) {
         cnt += lp.tf_cls_cnt[cls];
         maxm = std::max(maxm, lp.tf_cls_maxm[cls]);
@@ -3713,7 +3847,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
         if (cnt == 0 || (later > 0 && (narrow || cnt < 512))) continue;
         const TinyFrontTask* tf = static_cast<const TinyFrontTask*>(F.tftasks) + beg;
         const int tri = (maxm * (maxm + 1) / 2 + 1) & ~1;
-#define GSLS_FW_ARGS tf, cnt, pj, F.cmap, F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, \
+#define GSLS_FW_ARGS tf, cnt, gl, F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, \
                      F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri
         switch (cls) {
           case 0:
@@ -3725,8 +3859,11 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
           case 2:
             hipLaunchKernelGGL((k_front_wave<32, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
             break;
+          case 3:
+            hipLaunchKernelGGL((k_front_wave<48, 2>), dim3((cnt + 1) / 2), dim3(128), size_t(2) * tri * 8, st, GSLS_FW_ARGS);
+            break;
           default:
-            hipLaunchKernelGGL((k_front_wave<TINY_N, 2>), dim3((cnt + 1) / 2), dim3(128), size_t(2) * tri * 8, st, GSLS_FW_ARGS);
+            hipLaunchKernelGGL((k_front_lds<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
         }
 #undef GSLS_FW_ARGS
         beg += cnt;

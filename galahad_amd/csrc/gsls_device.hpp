@@ -49,8 +49,8 @@ struct LevelPlan {
   int tile_begin, tile_cnt;                 // range in the TileTask array
   int tinyc_begin, tinyc_cnt;               // fronts with a tiny contribution block (k_contrib_tiny)
   int tf_begin = 0, tf_cnt = 0;             // whole tiny fronts (k_front_wave), only in planT
-  int tf_cls_cnt[4] = {0, 0, 0, 0};         // ... by width class (24 / 28 / 32 / 48 columns), in that order
-  int tf_cls_maxm[4] = {0, 0, 0, 0};        // tallest front of each class (sizes the LDS triangle)
+  int tf_cls_cnt[5] = {0, 0, 0, 0, 0};      // ... by width class (24 / 28 / 32 / 48 / 64 columns), in that order
+  int tf_cls_maxm[5] = {0, 0, 0, 0, 0};     // tallest front of each class (sizes the LDS triangle)
   int pull_begin, pull_cnt;                 // extend-add tasks of the level (k_assemble_pull)
   int small_begin, small_cnt, small_maxn, small_maxm;   // solve: one-workgroup fronts
   int tiny32_cnt = 0;                       // ... of which the first tiny32_cnt have n <= 32
@@ -86,7 +86,9 @@ struct DeviceFactor {
   void* bl_pullsegs = nullptr;     // extend-add of the blacklisted fronts (k_front_wave assembles the others itself)
   void* bl_pulltasks = nullptr;
   int bl_count = 0;
-  void* pulljobs = nullptr;        // k_front_wave: one job per column of every child's contribution block
+  uint32_t* gdst = nullptr;        // k_front_wave: extend-add as a gather (GatherLists in gsls_device.hip)
+  int32_t* gbeg = nullptr;
+  int64_t* gsrc = nullptr;
   int32_t* aloc = nullptr;         // ... and the position of every entry of A in its front's LDS triangle
   int64_t* asrc_wg = nullptr;      // A -> L scatter restricted to the workgroup fronts of planT
   int64_t* adst_wg = nullptr;

@@ -4,7 +4,7 @@ import numpy as np, problems as P
 from galahad_amd import SLS, SMT, Control, InformSLS
 import galahad_amd._lib as L
 raw=C.CDLL(L.LIB_PATH)
-prob=P.kkt_qpband(100000,20000)
+prob=P.kkt_qpband(1000000,200000)
 n,row,col,val,rhs,xs=prob
 m=SMT(n,"COORDINATE",row=row,col=col,val=val)
 s,ct,i=SLS(),Control(),InformSLS(); s.initialize('gsls',ct,i); ct.pivot_control=1; ct.node_amalgamation=24
@@ -12,5 +12,5 @@ s.analyse(m,ct,i)
 for rep in range(3):
     s.factorize(m,ct,i)
     st=(C.c_ulonglong*64)(); raw.gsls_debug_stamps(st)
-    v=[st[k] for k in range(49,56)]
-    print('status',i.status,'cycles: task->loads issued %d | pivots (incl. load wait) %d | store %d | contrib %d | total %d'%(v[1]-v[0], v[2]-v[1], v[3]-v[2], v[4]-v[3], v[4]-v[0]))
+    v=[st[k] for k in range(49,53)]; w=[st[56]]
+    print('status',i.status,'root front, 100 MHz ticks: A part %d | children %d | pivots %d | outputs %d'%(w[0]-v[0], v[1]-w[0], v[2]-v[1], v[3]-v[2]))
