@@ -1021,6 +1021,7 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
   if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->kt_fwd = ms * 1e-3;
   if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->kt_diag = ms * 1e-3;
   if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->kt_bwd = ms * 1e-3;
+  (void)hipGetLastError();      // (an event that was never recorded must not surface as the next call's error)
   inform->time_solve = now() - t0;
   if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] solve job %d nrhs %d: %.3f ms\n", job, nrhs, inform->time_solve * 1e3);
   inform->solve_bytes = 2 * 8 * S.num_factor + (h->posdef ? 0 : 16 * int64_t(S.n)) + 32 * int64_t(S.n);

@@ -2289,6 +2289,212 @@ k_solve_bwd_chol(const SolveTask* __restrict__ tasks, const int32_t* __restrict_
 }
 
 // =================================================================================================
+// The same two Cholesky solve kernels for R right-hand sides at once (ssids_solve_mult, ssids.f90:1139-1249; the
+// reference's kernel takes nrhs columns through trsm/gemm, cholesky.cxx:191-212): L and W are read ONCE for all R
+// columns.  The front's vector becomes an m x R panel in LDS, r[i * R + c] (the R values of a row are contiguous: one
+// broadcast read feeds R FMAs); xp and cvec hold R copies, `xs` and `cs` elements apart.  Column c of the result is
+// bit-identical to the single-column kernels' (same operations in the same order per column).
+// =================================================================================================
+constexpr size_t MR_LDS_CAP = 150 * 1024;     // dynamic LDS the multi-column kernels may ask for
+template <int R>
+__global__ void __launch_bounds__(256)
+k_solve_fwd_chol_mr(const NodeDesc* __restrict__ nodes, const SolveTask* __restrict__ tasks,
+                    const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
+                    const double* __restrict__ L, const double* __restrict__ Linv,
+                    double* __restrict__ xp, double* __restrict__ cvec, int64_t xs, int64_t cs) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const SolveTask nd = tasks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int n = nd.n, m = nd.m, cm = m - n;
+  double* r = sh;                               // m x R
+  double* part = sh + ((m + 63) & ~63) * R;     // 4 x 64 x R
+  const double* Lb = L + nd.loff;
+  const double* Wn = Linv + int64_t(nd.iblk) * (NB * NB);
+  double w[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) w[t] = Wn[64 * lane + 16 * q + t];
+  const int nb0 = min(64, n);
+  double la[64];
+  load_row64(la, Lb, nd.ld, 0, nb0, nb0 + tid, m);
+  for (int i = tid; i < n; i += 256)
+#pragma unroll
+    for (int c = 0; c < R; ++c) r[i * R + c] = xp[c * xs + nd.sptr + i];
+  for (int i = n + tid; i < m; i += 256)
+#pragma unroll
+    for (int c = 0; c < R; ++c) r[i * R + c] = 0.0;
+  __syncthreads();
+  for (int ci = nd.cbeg; ci < nd.cend; ++ci) {    // children's contribution vectors, one child after the other
+    const NodeDesc cn = nodes[clist[ci]];
+    const int ccm = cn.m - cn.n;
+    const int32_t* map = cmap + cn.moff;
+    const double* cv = cvec + cn.moff;
+    for (int i = tid; i < ccm; i += 256) {
+      const int mi = map[i];
+#pragma unroll
+      for (int c = 0; c < R; ++c) r[mi * R + c] += cv[c * cs + i];
+    }
+    __syncthreads();
+  }
+  auto apply = [&](const double (&l)[64], int b, int nb, int i) {
+    double sacc[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) sacc[c] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      const double* rr = r + (b + (k < nb ? k : 0)) * R;
+#pragma unroll
+      for (int c = 0; c < R; ++c) sacc[c] += l[k] * rr[c];
+    }
+    if (i < m)
+#pragma unroll
+      for (int c = 0; c < R; ++c) r[i * R + c] -= sacc[c];
+  };
+  for (int b = 0; b < n; b += 64) {
+    const int nb = min(64, n - b);
+    const int below = b + nb;
+    {
+      double sacc[R];
+#pragma unroll
+      for (int c = 0; c < R; ++c) sacc[c] = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const bool on = 16 * q + t < nb;
+        const double* rr = r + (b + (on ? 16 * q + t : 0)) * R;
+#pragma unroll
+        for (int c = 0; c < R; ++c) sacc[c] += w[t] * (on ? rr[c] : 0.0);
+      }
+#pragma unroll
+      for (int c = 0; c < R; ++c) part[(q * 64 + lane) * R + c] = sacc[c];
+    }
+    __syncthreads();
+    if (b + 64 < n) {   // next block's W
+      const double* W2 = Wn + int64_t((b >> 6) + 1) * (NB * NB);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) w[t] = W2[64 * lane + 16 * q + t];
+    }
+    if (tid < nb)
+#pragma unroll
+      for (int c = 0; c < R; ++c)
+        r[(b + tid) * R + c] = (part[tid * R + c] + part[(64 + tid) * R + c]) +
+                               (part[(128 + tid) * R + c] + part[(192 + tid) * R + c]);
+    __syncthreads();
+    for (int c0 = below; c0 < m; c0 += 256) {
+      const int i = c0 + tid;
+      if (c0 > below) load_row64(la, Lb, nd.ld, b, nb, i, m);
+      apply(la, b, nb, i);
+    }
+    __syncthreads();
+    if (b + 64 < n) load_row64(la, Lb, nd.ld, b + 64, min(64, n - b - 64), b + 64 + min(64, n - b - 64) + tid, m);
+  }
+  for (int i = tid; i < n; i += 256)
+#pragma unroll
+    for (int c = 0; c < R; ++c) xp[c * xs + nd.sptr + i] = r[i * R + c];
+  double* mine = cvec + nd.moff;
+  for (int i = tid; i < cm; i += 256)
+#pragma unroll
+    for (int c = 0; c < R; ++c) mine[c * cs + i] = r[(n + i) * R + c];
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+k_solve_bwd_chol_mr(const SolveTask* __restrict__ tasks, const int32_t* __restrict__ rlist,
+                    const double* __restrict__ L, const double* __restrict__ Linv, double* __restrict__ xp,
+                    int64_t xs) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const SolveTask nd = tasks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int n = nd.n, m = nd.m;
+  double* blk = sh;                        // 64 x SB tile of L, transposed access
+  double* part = sh + 64 * SB;             // 4 x 64 x R
+  double* z = part + 256 * R;              // 64 x R
+  double* r = z + 64 * R;                  // m x R
+  const double* Lb = L + nd.loff;
+  const double* Wn = Linv + int64_t(nd.iblk) * (NB * NB);
+  const int32_t* rl = rlist + nd.roff;
+  for (int i = tid; i < n; i += 256)
+#pragma unroll
+    for (int c = 0; c < R; ++c) r[i * R + c] = xp[c * xs + nd.sptr + i];
+  for (int i = n + tid; i < m; i += 256) {
+    const int src = rl[i];
+#pragma unroll
+    for (int c = 0; c < R; ++c) r[i * R + c] = xp[c * xs + src];
+  }
+  for (int b = ((n - 1) >> 6) << 6; b >= 0; b -= 64) {
+    const int nb = min(64, n - b);
+    const int below = b + nb;
+    double w[16];
+    const double* Wb = Wn + int64_t(b >> 6) * (NB * NB);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = Wb[lane + 64 * (16 * q + t)];
+    double sacc[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) sacc[c] = 0.0;
+    double v[16];
+    auto load_tile = [&](int i0) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = tid + 256 * t;
+        const int i = e & 63, k = e >> 6;
+        v[t] = (i0 + i < m && k < nb) ? Lb[int64_t(b + k) * nd.ld + i0 + i] : 0.0;
+      }
+    };
+    if (below < m) load_tile(below);
+    __syncthreads();
+    for (int i0 = below; i0 < m; i0 += 64) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = tid + 256 * t;
+        blk[(e >> 6) * SB + (e & 63)] = v[t];
+      }
+      __syncthreads();
+      if (i0 + 64 < m) load_tile(i0 + 64);
+      const int lim = min(16, m - i0 - 16 * q);
+#pragma unroll 4
+      for (int i = 0; i < lim; ++i) {
+        const double lv = blk[lane * SB + 16 * q + i];
+        const double* rr = r + (i0 + 16 * q + i) * R;
+#pragma unroll
+        for (int c = 0; c < R; ++c) sacc[c] += lv * rr[c];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < R; ++c) part[(q * 64 + lane) * R + c] = sacc[c];
+    __syncthreads();
+    if (tid < 64)
+#pragma unroll
+      for (int c = 0; c < R; ++c)
+        z[tid * R + c] = (tid < nb) ? r[(b + tid) * R + c] - ((part[tid * R + c] + part[(64 + tid) * R + c]) +
+                                                              (part[(128 + tid) * R + c] + part[(192 + tid) * R + c]))
+                                    : 0.0;
+    __syncthreads();
+    {
+      double xacc[R];
+#pragma unroll
+      for (int c = 0; c < R; ++c) xacc[c] = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const double* zz = z + (16 * q + t) * R;
+#pragma unroll
+        for (int c = 0; c < R; ++c) xacc[c] += w[t] * zz[c];
+      }
+#pragma unroll
+      for (int c = 0; c < R; ++c) part[(q * 64 + lane) * R + c] = xacc[c];
+    }
+    __syncthreads();
+    if (tid < nb)
+#pragma unroll
+      for (int c = 0; c < R; ++c)
+        r[(b + tid) * R + c] = (part[tid * R + c] + part[(64 + tid) * R + c]) +
+                               (part[(128 + tid) * R + c] + part[(192 + tid) * R + c]);
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256)
+#pragma unroll
+    for (int c = 0; c < R; ++c) xp[c * xs + nd.sptr + i] = r[i * R + c];
+}
+
+// =================================================================================================
 // LDL^T solves for TINY fronts (n <= 64 pivots, m - n <= 64 rows below): one WAVE per front, four fronts per
 // workgroup, no barriers.  Trees of saddle-point systems are tens of thousands of such fronts; a
 // workgroup per front left the CU mostly idle.  Row/column of the front live in registers, the
@@ -2658,14 +2864,23 @@ __device__ __forceinline__ void wave_fwd_compute(const WTask& t, int lane, const
   const int m = t.m, n = t.n;
   // analyse-time row `lane` of the front: right-hand side + (sum of the children's contributions)
   double csum = 0.0;
-  if (PULLS && (t.flags & WT_PULL) && lane < m) {
-    const int g0 = gth_ptr[t.goff + lane], g1 = gth_ptr[t.goff + lane + 1];
-    int g = g0;
-    for (; g + 4 <= g1; g += 4) {       // four sources in flight at a time; summed in list order
-      const double c0 = cvec[gth_src[g]], c1 = cvec[gth_src[g + 1]], c2 = cvec[gth_src[g + 2]], c3 = cvec[gth_src[g + 3]];
-      csum = (((csum + c0) + c1) + c2) + c3;
+  if (PULLS && (t.flags & WT_PULL)) {   // (wave-uniform: every lane walks the loop, rows without sources add nothing)
+    const int lr = min(lane, m - 1);
+    const int g0 = gth_ptr[t.goff + lr], g1 = (lane < m) ? gth_ptr[t.goff + lr + 1] : g0;
+    const int last = max(g1 - 1, g0);   // (g0 is a valid index whenever the front has any source at all)
+    // eight sources in flight, their indices fetched one round ahead; summed in list order
+    int64_t idx[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) idx[q] = gth_src[min(g0 + q, last)];
+    for (int g = g0; __any(g < g1); g += 8) {
+      double c[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) c[q] = cvec[idx[q]];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) idx[q] = gth_src[min(g + 8 + q, last)];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) csum += (g + q < g1) ? c[q] : 0.0;
     }
-    for (; g < g1; ++g) csum += cvec[gth_src[g]];
   }
   if (t.flags & WT_INT) {
     double* mine = acc + t.myslot * 64;
@@ -2780,9 +2995,18 @@ __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const
     }
   }
   if (t.flags & WT_INT) xfull[t.myslot * 64 + lane] = x;       // for the children inside the group
-  if (PULLS && (t.flags & WT_PULL) && lane < m) {              // ... and for those of earlier stages
-    const int g0 = gth_ptr[t.goff + lane], g1 = gth_ptr[t.goff + lane + 1];
-    for (int g = g0; g < g1; ++g) cvec[gth_src[g]] = x;
+  if (PULLS && (t.flags & WT_PULL)) {                          // ... and for those of earlier stages
+    const int lr = min(lane, m - 1);
+    const int g0 = gth_ptr[t.goff + lr], g1 = (lane < m) ? gth_ptr[t.goff + lr + 1] : g0;
+    const int last = max(g1 - 1, g0);
+    for (int g = g0; __any(g < g1); g += 8) {                  // eight destinations' indices in flight at a time
+      int64_t idx[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) idx[q] = gth_src[min(g + q, last)];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (g + q < g1) cvec[idx[q]] = x;
+    }
   }
   if (lane < n) {
     xp[p.pos] = x;
@@ -3149,7 +3373,7 @@ extern "C" void gsls_debug_stamps(unsigned long long* out) {
 
 void dev_free(DeviceFactor& F) {
   void* ptrs[] = {F.nodes, F.rlist, F.cmap, F.clist, F.lvlnodes, F.pullsegs, F.tinyctasks, F.tftasks, F.asrc, F.adst, F.arow,
-                  F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec,
+                  F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec, F.xp_mr, F.cvec_mr,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
                   F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
@@ -3167,6 +3391,12 @@ void dev_free(DeviceFactor& F) {
 
 static hipError_t allow_big_lds() {
   const int big = 160 * 1024 - 512;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_chol_mr<8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_chol_mr<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_chol_mr<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_fast<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
@@ -3226,9 +3456,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   std::vector<PullSeg> psg;
   std::vector<TinyContribTask> tct;
   std::vector<TinyFrontTask> tft;
-  std::vector<uint32_t> gdst;
-  std::vector<int32_t> gbeg;
-  std::vector<int64_t> gsrc;
+  std::vector<uint32_t> fgdst;      // k_front_wave: extend-add gather lists
+  std::vector<int32_t> fgbeg;
+  std::vector<int64_t> fgsrc;
   std::vector<std::pair<int32_t, int64_t>> gtmp;
   std::vector<PullTask> ptk;
   std::vector<int32_t> smalln, bign;
@@ -3297,7 +3527,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         const int s = lvl_nodes[i];
         if (wg(s) || tiny_class(S.ncol(s)) != cls) continue;
         TinyFrontTask tk{S.ncol(s), S.nrow(s), S.ldl[s], S.sptr[s], S.loff[s], S.coff[s], nd[s].iblk,
-                         (S.sparent[s] < nn) ? 1 : 0, s, 0, 0, 0, int64_t(gdst.size()), int64_t(gsrc.size()),
+                         (S.sparent[s] < nn) ? 1 : 0, s, 0, 0, 0, int64_t(fgdst.size()), int64_t(fgsrc.size()),
                          S.nptr[s], int32_t(S.nptr[s + 1] - S.nptr[s]), 0};
         gtmp.clear();
         const int pm = S.nrow(s);
@@ -3314,12 +3544,12 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         for (size_t e = 0; e < gtmp.size();) {
           size_t e2 = e;
           while (e2 < gtmp.size() && gtmp[e2].first == gtmp[e].first) ++e2;
-          gdst.push_back(uint32_t(gtmp[e].first) | (uint32_t(e2 - e) << 12));
-          gbeg.push_back(int32_t(int64_t(gsrc.size()) - tk.s0));
-          for (size_t q = e; q < e2; ++q) gsrc.push_back(gtmp[q].second);
+          fgdst.push_back(uint32_t(gtmp[e].first) | (uint32_t(e2 - e) << 12));
+          fgbeg.push_back(int32_t(int64_t(fgsrc.size()) - tk.s0));
+          for (size_t q = e; q < e2; ++q) fgsrc.push_back(gtmp[q].second);
           e = e2;
         }
-        tk.nd = int32_t(int64_t(gdst.size()) - tk.d0);
+        tk.nd = int32_t(int64_t(fgdst.size()) - tk.d0);
         tft.push_back(tk);
         lp.tf_cls_maxm[cls] = std::max(lp.tf_cls_maxm[cls], S.nrow(s));
         lp.tf_cls_cnt[cls]++;
@@ -3519,7 +3749,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       {
         std::vector<int64_t> stage_tasks(nstage, 0);
         for (const GInfo& g : gi) stage_tasks[g.stage] += g.cnt;
-        const int wslots = getenv("GSLS_WSLOTS") ? std::max(1, atoi(getenv("GSLS_WSLOTS"))) : 4096;
+        const int wslots = getenv("GSLS_WSLOTS") ? std::max(1, atoi(getenv("GSLS_WSLOTS"))) : 16384;
         int64_t tb = 0;
         int cur_stage = -1, cur_wide = -1, cur_cnt = 0, target = 1;
         for (size_t g = 0; g < gi.size(); ++g) {
@@ -3592,6 +3822,25 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         }
         gptr.push_back(int32_t(gsrc.size()));   // one spare entry: every task owns m + 1 consecutive pointers
       }
+      if (getenv("GSLS_DEBUG"))
+        for (int sg = 0; sg < nstage; ++sg) {
+          int runs = F.wstage_cnt[sg], maxrun = 0, maxn = 0, maxm = 0, npull = 0, ntask = 0, maxsrc = 0;
+          for (int r = F.wstage_begin[sg]; r < F.wstage_begin[sg] + runs; ++r) {
+            maxrun = std::max(maxrun, int(wg[r].tcnt));
+            for (int64_t ti = wg[r].tbeg; ti < wg[r].tbeg + wg[r].tcnt; ++ti) {
+              ++ntask;
+              maxn = std::max(maxn, int(wt[ti].n));
+              maxm = std::max(maxm, int(wt[ti].m));
+              if (wt[ti].flags & WT_PULL) {
+                ++npull;
+                for (int r2 = 0; r2 < wt[ti].m; ++r2)
+                  maxsrc = std::max(maxsrc, int(gptr[wt[ti].goff + r2 + 1] - gptr[wt[ti].goff + r2]));
+              }
+            }
+          }
+          fprintf(stderr, "[gsls] wave stage %d: %d runs (%d narrow), %d fronts, longest run %d, max n %d m %d, %d pulling fronts (longest row list %d)\n",
+                  sg, runs, F.wstage_narrow[sg], ntask, maxrun, maxn, maxm, npull, maxsrc);
+        }
       for (auto& tk : tft) {
         tk.lfoff = nlf[tk.node];
         tk.lboff = nlb[tk.node];
@@ -3614,6 +3863,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         F.wgroups = d2;
         F.wpacks = d3;
       }
+      gsrc.insert(gsrc.end(), 16, 0);            // (the pipelined gathers read one clamped index past a row's list)
       HIPCHK(upload(F.wgth_ptr, gptr, st));
       HIPCHK(upload(F.wgth_src, gsrc, st));
       HIPCHK(upload(F.wnont, nont, st));
@@ -3757,9 +4007,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     TinyFrontTask* d4 = nullptr;
     HIPCHK(upload(d4, tft, st));
     F.tftasks = d4;
-    HIPCHK(upload(F.gdst, gdst, st));
-    HIPCHK(upload(F.gbeg, gbeg, st));
-    HIPCHK(upload(F.gsrc, gsrc, st));
+    HIPCHK(upload(F.gdst, fgdst, st));
+    HIPCHK(upload(F.gbeg, fgbeg, st));
+    HIPCHK(upload(F.gsrc, fgsrc, st));
   }
   HIPCHK(upload(F.aloc, aloc, st));
   HIPCHK(upload(F.asrc, asrc, st));
@@ -4350,8 +4600,78 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   return hipGetLastError();
 }
 
+// Cholesky sweeps for R right-hand sides at once (every front of the plan on the one-workgroup kernels)
+static size_t mr_lds_fwd(int maxm, int R) { return sizeof(double) * (size_t((maxm + 63) & ~63) * R + 256 * R); }
+static size_t mr_lds_bwd(int maxm, int R) { return sizeof(double) * (64 * SB + 256 * R + 64 * R + size_t(std::max(maxm, 1)) * R); }
+template <int R>
+static hipError_t solve_sweeps_mr(const Symbolic& S, DeviceFactor& F, int job, hipStream_t st) {
+  const bool do_fwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
+  const bool do_bwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD || job == GSLS_SOLVE_JOB_DIAG_BWD);
+  const int64_t xs = F.xs_mr, cs = F.cs_mr;
+  const SolveTask* stk = static_cast<const SolveTask*>(F.stasks);
+  if (do_fwd)
+    for (int l = 0; l < S.nlevels; ++l) {
+      const LevelPlan& lp = F.plan[l];
+      if (lp.small_cnt > 0)
+        hipLaunchKernelGGL(k_solve_fwd_chol_mr<R>, dim3(lp.small_cnt), dim3(256), mr_lds_fwd(lp.small_maxm, R), st, F.nodes,
+                           stk + lp.small_begin, F.clist, F.cmap, F.L, F.Linv, F.xp_mr, F.cvec_mr, xs, cs);
+    }
+  if (do_bwd)
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+      const LevelPlan& lp = F.plan[l];
+      if (lp.small_cnt > 0)
+        hipLaunchKernelGGL(k_solve_bwd_chol_mr<R>, dim3(lp.small_cnt), dim3(256), mr_lds_bwd(lp.small_maxm, R), st,
+                           stk + lp.small_begin, F.rlist, F.L, F.Linv, F.xp_mr, xs);
+    }
+  return hipGetLastError();
+}
+// widest block the plan admits: 0 if some front needs the blocked multi-launch kernels or the panel does not fit in LDS
+static int mr_width(const Symbolic& S, const DeviceFactor& F, int nrhs) {
+  int maxm = 0;
+  for (int l = 0; l < S.nlevels; ++l) {
+    if (F.plan[l].big_cnt > 0) return 0;
+    if (F.plan[l].small_cnt > 0) maxm = std::max(maxm, F.plan[l].small_maxm);
+  }
+  for (int R : {8, 4, 2})
+    if (R <= nrhs && mr_lds_fwd(maxm, R) <= MR_LDS_CAP && mr_lds_bwd(maxm, R) <= MR_LDS_CAP) return R;
+  return 0;
+}
+
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev) {
+  int r0 = 0;
+  if (posdef && nrhs >= 2 && S.n > 0 && !F.sharded && !getenv("GSLS_NO_MULTIRHS")) {
+    // blocks of 8 / 4 / 2 columns through the multi-column kernels: one pass over L per block
+    const int blocks = (S.n + 255) / 256;
+    const bool scale_in = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
+    const bool scale_out = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD ||
+                                       job == GSLS_SOLVE_JOB_DIAG_BWD);
+    while (true) {
+      const int R = mr_width(S, F, nrhs - r0);
+      if (R == 0) break;
+      if (ev && r0 == 0) HIPCHK(hipEventRecord(ev[0], st));
+      if (!F.xp_mr) {
+        F.xs_mr = ((int64_t(S.n) + 64 + 15) / 16) * 16;
+        F.cs_mr = ((std::max<int64_t>(F.cvec_elems, 1) + 64 + 15) / 16) * 16;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp_mr), 8 * F.xs_mr * sizeof(double)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec_mr), 8 * F.cs_mr * sizeof(double)));
+        HIPCHK(hipMemsetAsync(F.xp_mr, 0, 8 * F.xs_mr * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(F.cvec_mr, 0, 8 * F.cs_mr * sizeof(double), st));
+      }
+      for (int c = 0; c < R; ++c)
+        hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, d_x + int64_t(r0 + c) * ldx,
+                           scale_in ? d_scale : nullptr, F.xp_mr + c * F.xs_mr);
+      hipError_t e = R == 8 ? solve_sweeps_mr<8>(S, F, job, st)
+                   : R == 4 ? solve_sweeps_mr<4>(S, F, job, st) : solve_sweeps_mr<2>(S, F, job, st);
+      if (e != hipSuccess) return e;
+      for (int c = 0; c < R; ++c)
+        hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.xp_mr + c * F.xs_mr,
+                           scale_out ? d_scale : nullptr, d_x + int64_t(r0 + c) * ldx);
+      r0 += R;
+    }
+    if (ev && r0 >= nrhs && r0 > 0)        // (no single column follows: the phase events bracket the blocked sweeps)
+      for (int k = 1; k < 4; ++k) HIPCHK(hipEventRecord(ev[k], st));
+  }
   if (F.nrhs_cap < 1) {
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));
     HIPCHK(hipMemsetAsync(F.xp, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
@@ -4361,7 +4681,7 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
   const bool wave = F.wave && !posdef;
   const bool has_bwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD || job == GSLS_SOLVE_JOB_DIAG_BWD);
   // which side of the permutation/scaling each job touches (fkeep.F90:229-318)
-  for (int r = 0; r < nrhs; ++r) {
+  for (int r = r0; r < nrhs; ++r) {
     double* x = d_x + int64_t(r) * ldx;
     if (S.n == 0) continue;
     const bool scale_in = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
@@ -4372,7 +4692,7 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
     const bool fuse_out = wave && has_bwd;
     hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
                          scale_in ? d_scale : nullptr, F.xp);
-    hipEvent_t* evr = (r == 0) ? ev : nullptr;
+    hipEvent_t* evr = (r == r0) ? ev : nullptr;
     hipError_t e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, evr)
                    : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, nullptr,
                                                 fuse_out ? x : nullptr, scale_out ? d_scale : nullptr)

@@ -94,6 +94,9 @@ struct DeviceFactor {
   int64_t* adst_wg = nullptr;
   int64_t nscatter_wg = 0;
   const double* cur_val = nullptr; // the values of the factorization in flight
+  double* xp_mr = nullptr;         // multi-column solves: up to 8 permuted vectors, xs_mr elements apart,
+  double* cvec_mr = nullptr;       // and 8 copies of the contribution vectors, cs_mr apart
+  int64_t xs_mr = 0, cs_mr = 0;
   std::vector<BlLevel> bl_level;
   int32_t* smallnodes = nullptr;
   void* stasks = nullptr;          // SolveTask per entry of smallnodes (same indexing)

@@ -635,3 +635,30 @@ def test_value_map_and_residual_on_device():
     assert P.scaled_residual(n, row[:-2], col[:-2], val2[:-2], xr, rhs) <= 1e-14
     s.terminate()
     s2.terminate()
+
+
+@pytest.mark.parametrize("nrhs", [2, 3, 8, 13])
+def test_blocked_multi_rhs_equals_column_by_column(nrhs):
+    """SLS_solve with several right-hand sides (ssids_solve_mult, ssids.f90:1139-1249): the Cholesky path takes blocks of
+    8 / 4 / 2 columns through one pass over L (k_solve_*_chol_mr).  Every column must carry exactly the bits the
+    single-column kernels produce, for the whole solve and for the partial solves (job L and U)."""
+    prob = P.banded_spd(6000, 47, seed=3)
+    n, row, col, val, rhs, xs = prob
+    s, m, c, i = run_gsls(prob, True)
+    assert i.status == 0
+    c.max_iterative_refinements = 0
+    rng = np.random.default_rng(nrhs)
+    B = np.asfortranarray(rng.uniform(-1, 1, (n, nrhs)))
+    X = s.solve(m, B, c, i)
+    assert i.status == 0 and X.shape == (n, nrhs)
+    for k in range(nrhs):
+        xk = s.solve(m, B[:, k].copy(), c, i)
+        assert np.array_equal(X[:, k], xk), k
+        assert P.scaled_residual(n, row, col, val, X[:, k], B[:, k]) <= 1e-13
+    Y = s.part_solve("L", B, c, i)
+    Z = s.part_solve("U", Y, c, i)
+    for k in range(nrhs):
+        yk = s.part_solve("L", B[:, k].copy(), c, i)
+        assert np.array_equal(Y[:, k], yk)
+    assert np.array_equal(Z, X)
+    s.terminate()
