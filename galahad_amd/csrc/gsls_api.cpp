@@ -31,6 +31,7 @@ struct Handle {
   bool tiny_ready = false;    // the order is learned: tiny fronts may go through the wave-per-front kernel
   int tiny_strikes = 0;       // factorizations in which that kernel met a pivot it could not take
   std::vector<int> tiny_black;   // tiny fronts that kernel gave up on: they stay on the workgroup path
+  std::vector<double> scale_host; // the scaling the last factorization computed itself (options.scaling > 0), else empty
   int last_fast = 0, last_pivoted = 0, last_passes = 0;   // of the last factorization (gsls_get_factor_stats)
   bool own_order = false;     // analyse chose the elimination order itself (it may be refined when values arrive)
   bool preordered = false;    // ... and that refinement (zero-diagonal variables after their neighbours) has been done
@@ -528,6 +529,40 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     if (rf < 0) return inform->flag = rf;
   }
   DeviceFactor& F = h->F;
+  // ---- the reference's internal scalings (ssids.f90:921-1030), computed on the host from these values ------------
+  std::vector<double> own_scale;
+  if (!scale && options->scaling > 0) {
+    if (options->scaling == 3) return inform->flag = GSLS_ERROR_NO_SAVED_SCALING;   // needs the matching-based ordering
+    const int n = S.n;
+    const int64_t nzv = h->ptr[n] - 1;
+    std::vector<double> hv;
+    const double* v = val;
+    if (on_device) {
+      hv.resize(size_t(nzv));
+      e = hipMemcpyAsync(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);    // (the value map of gsls_factor_coo runs on this stream)
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      v = hv.data();
+    }
+    std::vector<int64_t> p0(n + 1);
+    std::vector<int32_t> r0(static_cast<size_t>(nzv));
+    for (int j = 0; j <= n; ++j) p0[j] = h->ptr[j] - 1;
+    for (int64_t k = 0; k < nzv; ++k) r0[k] = h->row[k] - 1;
+    own_scale.resize(n);
+    int sf = 0;
+    try {
+      if (options->scaling == 1) sf = hungarian_scale_sym(n, p0.data(), r0.data(), v, options->action != 0, own_scale.data());
+      else if (options->scaling == 2) sf = auction_scale_sym(n, p0.data(), r0.data(), v, own_scale.data());
+      else sf = equilib_scale_sym(n, p0.data(), r0.data(), v, own_scale.data());
+    } catch (const std::bad_alloc&) {
+      return inform->flag = GSLS_ERROR_ALLOCATION;
+    }
+    if (sf == -2) return inform->flag = GSLS_ERROR_SINGULAR;    // structurally singular and action = false (ssids.f90:944-947)
+    scale = own_scale.data();      // a HOST vector whatever `on_device` says about the values (see stage_inputs)
+    h->scale_host = own_scale;
+  } else if (!scale) {
+    h->scale_host.clear();
+  }
   const double* d_val = val;
   const double* d_scale = scale;
   auto stage_inputs = [&]() -> hipError_t {
@@ -550,8 +585,9 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
         hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&F.scale), h->S.n * sizeof(double));
         if (e2 != hipSuccess) return e2;
       }
+      const bool host_vec = !on_device || !own_scale.empty();
       hipError_t e2 = hipMemcpyAsync(F.scale, scale, h->S.n * sizeof(double),
-                                     on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream);
+                                     host_vec ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream);
       if (e2 != hipSuccess) return e2;
       d_scale = F.scale;
     }
@@ -1575,6 +1611,39 @@ int gsls_get_order(void* handle, int32_t* order) {
   Handle* h = static_cast<Handle*>(handle);
   if (!h || !h->analysed || !order) return GSLS_ERROR_CALL_SEQUENCE;
   for (int i = 0; i < h->S.n; ++i) order[i] = h->S.perm[i] + 1;
+  return GSLS_SUCCESS;
+}
+
+// host utility: the scaling gsls_factor* would compute for options.scaling = kind (1, 2, 4) from these values, without a
+// handle or a device -- hungarian_scale_sym / auction_scale_sym / equilib_scale_sym of src/spral/scaling.f90.
+// ptr / row 1-based, lower triangle by columns.  Returns 0, 1 (structurally singular, scaled as the reference does
+// with action = true) or GSLS_ERROR_SINGULAR (action = false: identity scaling).
+int gsls_scale_sym(int32_t kind, int32_t n, const int64_t* ptr, const int32_t* row, const double* val, int32_t action,
+                   double* scaling) {
+  if (n < 0 || !ptr || !scaling || (n > 0 && (!row || !val))) return GSLS_ERROR_CALL_SEQUENCE;
+  if (kind != 1 && kind != 2 && kind != 4) return GSLS_ERROR_UNIMPLEMENTED;
+  try {
+    const int64_t nz = ptr[n] - 1;
+    std::vector<int64_t> p0(n + 1);
+    std::vector<int32_t> r0(static_cast<size_t>(nz));
+    for (int j = 0; j <= n; ++j) p0[j] = ptr[j] - 1;
+    for (int64_t k = 0; k < nz; ++k) r0[k] = row[k] - 1;
+    int sf;
+    if (kind == 1) sf = gsls::hungarian_scale_sym(n, p0.data(), r0.data(), val, action != 0, scaling);
+    else if (kind == 2) sf = gsls::auction_scale_sym(n, p0.data(), r0.data(), val, scaling);
+    else sf = gsls::equilib_scale_sym(n, p0.data(), r0.data(), val, scaling);
+    return sf == -2 ? GSLS_ERROR_SINGULAR : sf;
+  } catch (const std::bad_alloc&) {
+    return GSLS_ERROR_ALLOCATION;
+  }
+}
+
+// the scaling factors the last factorization computed itself (gsls_options.scaling = 1, 2, 4): what ssids_factor returns
+// in its optional `scale` argument (ssids.f90:955-958); GSLS_ERROR_CALL_SEQUENCE if that factorization did not scale
+int gsls_get_scaling(void* handle, double* scaling) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->factored || !scaling || int(h->scale_host.size()) != h->S.n) return GSLS_ERROR_CALL_SEQUENCE;
+  std::copy(h->scale_host.begin(), h->scale_host.end(), scaling);
   return GSLS_SUCCESS;
 }
 

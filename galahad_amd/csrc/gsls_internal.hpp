@@ -71,6 +71,12 @@ void shard_tree(Symbolic& S, int nranks);
 
 // offsets of the contribution blocks: reuse = true packs them by lifetime (single device), false lays them out one
 // after the other (multi-GPU: the cut roots' blocks must survive until the exchange)
+// gsls_scaling.cpp: the reference's internal scalings (spral/scaling.f90); lower triangle by columns, 0-based
+int hungarian_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, bool scale_if_singular,
+                        double* scaling);
+int auction_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, double* scaling);
+int equilib_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, double* scaling);
+
 void layout_contrib(Symbolic& S, bool reuse);
 void layout_contrib_auto(Symbolic& S);       // reuse when the blocks would not fit side by side comfortably
 

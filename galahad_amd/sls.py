@@ -247,6 +247,8 @@ class SLS:
     def _copy_control(self, control):
         """SLS_copy_control_to_ssids, src/sls/sls.f90:1385-1439"""
         self.opts.nemin = control.node_amalgamation
+        # control%scaling = -1 / -2 / -3 -> the backend's own scalings 1 / 2 / 3 (sls.f90:1405-1413)
+        self.opts.scaling = {-1: 1, -2: 2, -3: 3}.get(int(control.scaling), 0)
         self.opts.small = control.absolute_pivot_tolerance
         self.opts.print_level = control.print_level - 1
         if control.pivot_control == 2:

@@ -47,6 +47,7 @@ enum {
   GSLS_ERROR_JOB_OOR = -11,
   GSLS_ERROR_NOT_LLT = -13,
   GSLS_ERROR_NOT_LDLT = -14,
+  GSLS_ERROR_NO_SAVED_SCALING = -15, /* scaling = 3 without the matching-based ordering (ssids.f90:991-994)     */
   GSLS_ERROR_ALLOCATION = -50,
   GSLS_ERROR_HIP = -51,           /* SSIDS_ERROR_CUDA_UNKNOWN */
   GSLS_ERROR_UNIMPLEMENTED = -98,
@@ -77,7 +78,8 @@ typedef struct gsls_options {
   int32_t print_level;     /* <0 silent (default -1)                                            */
   int32_t ordering;        /* GSLS_ORDER_*                                                      */
   int32_t nemin;           /* supernode amalgamation, default 32 (core_analyse.f90:806-822)      */
-  int32_t scaling;         /* 0 none / user supplied `scale`                                     */
+  int32_t scaling;         /* 0 none / user supplied `scale`; 1 Hungarian (MC64), 2 auction, 4 norm     */
+                           /* equilibration, computed from the values (ssids.f90:921-1030); 3: -15       */
   int32_t action;          /* indefinite: continue on singularity with warning 7 (default 1)     */
   int32_t device;          /* HIP device ordinal, -1 = current device                            */
   int32_t reserved2;       /* (was use_graph: never implemented; launch gaps measure ~0, a graph would buy nothing) */
@@ -262,6 +264,17 @@ int gsls_comm_destroy(void* handle);
 int gsls_get_symbolic_sizes(void* handle, int32_t* nnodes, int64_t* rlist_len, int64_t* nlist_len);
 int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rptr, int32_t* rlist,
                       int64_t* nptr, int64_t* nlist);
+
+/* host utility (no handle, no device): the scaling gsls_factor* computes for options.scaling = kind (1 Hungarian,
+ * 2 auction, 4 norm equilibration) -- hungarian_scale_sym / auction_scale_sym / equilib_scale_sym of
+ * src/spral/scaling.f90:109-170, 245-309, 381-416.  ptr / row 1-based lower triangle by columns.
+ * Returns 0, 1 (structurally singular, scaled anyway because action != 0) or GSLS_ERROR_SINGULAR. */
+int gsls_scale_sym(int32_t kind, int32_t n, const int64_t* ptr, const int32_t* row, const double* val, int32_t action,
+                   double* scaling);
+
+/* the scaling factors the last factorization computed itself (options.scaling = 1, 2, 4), in the caller's
+ * variable order: the optional `scale` output of ssids_factor (src/ssids/ssids.f90:955-958, 983-986, 1021-1025) */
+int gsls_get_scaling(void* handle, double* scaling);
 
 /* the elimination order the handle currently holds (order[var] = 1-based pivot position): what analyse was
  * given or computed, as repaired by factorizations that met delayed pivots; a valid PERM for SLS_analyse */

@@ -218,6 +218,16 @@ COPY_ROUTINES = """
      control_gsls%print_level = control%print_level_solver - 1
      control_gsls%nemin = control%node_amalgamation
      control_gsls%small = control%absolute_pivot_tolerance
+!  the backend's own scalings, as for ssids (SLS_copy_control_to_ssids, :1405-1413)
+     IF ( control%scaling == - 1 ) THEN
+       control_gsls%scaling = 1
+     ELSE IF ( control%scaling == - 2 ) THEN
+       control_gsls%scaling = 2
+     ELSE IF ( control%scaling == - 3 ) THEN
+       control_gsls%scaling = 3
+     ELSE
+       control_gsls%scaling = 0
+     END IF
      IF ( control%pivot_control == 2 .OR. control%pivot_control == 4 ) THEN
        control_gsls%u = 0.0_wp ; control_gsls%action = 1
      ELSE IF ( control%pivot_control == 3 ) THEN

@@ -48,7 +48,7 @@ def case(name, prob, posdef, perm=None, nemin=32, nrhs=1):
         ref["delayed"], np.abs(ref["x"] - xs).max()))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "scaled" not in sys.argv[1:]:
     rng = np.random.default_rng(20240110)
     case("kat_indef_natural", P.kat_indefinite(), False)
     case("kat_indef_reverse", P.kat_indefinite(), False, perm=np.arange(5, 0, -1))   # slst.f90:54-56
@@ -67,3 +67,36 @@ if __name__ == "__main__":
     case("rand_indef_500", P.random_sparse(500, 5, 7, spd=False), False, perm=rng.permutation(500) + 1, nemin=8)
     case("diag_only_50", (50, np.arange(1, 51, dtype=np.int32), np.arange(1, 51, dtype=np.int32),
                           np.linspace(1, 5, 50), np.linspace(1, 5, 50) * 2.0, np.full(50, 2.0)), True)
+
+
+def scaled_case(name, prob, scaling, posdef=False, nemin=32):
+    """badly scaled system through the reference with control%scaling = -1 (Hungarian) / -2 (auction): what SLS's
+    ssids arm does with it (sls.f90:1405-1413 -> ssids.f90:921-990)"""
+    n, row, col, val, rhs, xs = prob
+    perm = np.arange(1, n + 1, dtype=np.int32)
+    ref = refio.run(n, row, col, val, rhs, perm=perm, nemin=nemin, scaling=scaling,
+                    pivot_control=2 if posdef else 1, threads=1)
+    plain = refio.run(n, row, col, val, rhs, perm=perm, nemin=nemin, pivot_control=2 if posdef else 1, threads=1)
+    assert ref["status_analyse"] == 0 and ref["status_factorize"] == 0 and ref["status_solve"] == 0, ref
+    out = dict(n=n, row=row, col=col, val=val, rhs=rhs, xstar=xs, perm=perm, nemin=nemin, posdef=int(posdef),
+               scaling=scaling, ref_x=ref["x"], ref_neg=ref["negative_eigenvalues"], ref_rank=ref["rank"],
+               ref_two=ref["two_by_two"], ref_delayed=ref["delayed"], ref_delayed_unscaled=plain["delayed"],
+               ref_x_unscaled=plain["x"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%-26s n=%-6d scaling=%d neg=%-5d two=%-4d delayed=%-4d (unscaled run: %d) err=%.2e (unscaled %.2e)" % (
+        name, n, scaling, ref["negative_eigenvalues"], ref["two_by_two"], ref["delayed"], plain["delayed"],
+        np.abs(ref["x"] - xs).max(), np.abs(plain["x"] - xs).max()))
+
+
+def badly_scaled(prob, seed, decades=4.0):
+    n, row, col, val, rhs, xs = prob
+    d = 10.0 ** np.random.default_rng(seed).uniform(-decades, decades, n)
+    val2 = val * d[row - 1] * d[col - 1]
+    return (n, row, col, val2, P.sym_matvec(n, row - 1, col - 1, val2, xs), xs)
+
+
+if __name__ == "__main__" and "scaled" in sys.argv[1:]:
+    for sc, tag in ((-1, "hungarian"), (-2, "auction")):
+        scaled_case("scaled_kkt_%s" % tag, badly_scaled(P.kkt_qpband(300, 60), 1), sc)
+        scaled_case("scaled_grid_indef_%s" % tag, badly_scaled(P.grid2d(15, 14, shift=1.0), 2), sc)
+        scaled_case("scaled_rand_indef_%s" % tag, badly_scaled(P.random_sparse(400, 5, 7, spd=False), 3), sc, nemin=8)

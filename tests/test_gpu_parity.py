@@ -18,7 +18,7 @@ import problems as P
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(p).startswith("scaled_"))
 EPS = np.finfo(float).eps
 
 
@@ -662,3 +662,45 @@ def test_blocked_multi_rhs_equals_column_by_column(nrhs):
         assert np.array_equal(Y[:, k], yk)
     assert np.array_equal(Z, X)
     s.terminate()
+
+
+SCALED = sorted(glob.glob(os.path.join(HERE, "golden", "scaled_*.npz")))
+
+
+@pytest.mark.parametrize("path", SCALED, ids=[os.path.basename(p)[:-4] for p in SCALED])
+def test_reference_scalings(path):
+    """control%scaling = -1 (Hungarian) / -2 (auction) on systems whose rows span eight decades, against the reference
+    run with the same control (fixtures from tests/golden/make_golden.py scaled).  The scale vectors are not unique, so
+    the comparison is what a caller sees: inertia, residual, the solution to the accuracy the reference itself reaches
+    against the generating x, and far fewer delayed pivots than without scaling (why the option exists)."""
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    g = np.load(path)
+    n = int(g["n"])
+    row, col, val, rhs = g["row"], g["col"], g["val"], g["rhs"]
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    out = {}
+    for scaling in (int(g["scaling"]), 0):
+        s, c, i = SLS(), Control(), InformSLS()
+        s.initialize("gsls", c, i)
+        c.pivot_control, c.node_amalgamation, c.scaling = 1, int(g["nemin"]), scaling
+        c.max_iterative_refinements = 0
+        s.analyse(m, c, i, PERM=g["perm"])
+        s.factorize(m, c, i)
+        assert i.status == 0, i.gsls_inform
+        x = s.solve(m, rhs, c, i)
+        out[scaling] = (x, i.delayed_pivots, i.negative_eigenvalues, i.rank)
+        if scaling != 0:
+            sc = np.zeros(n)
+            from galahad_amd._lib import lib
+            import ctypes as C
+            assert lib.gsls_get_scaling(s.handle, sc.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            sv = np.abs(val) * sc[row - 1] * sc[col - 1]
+            assert sv.max() <= (1.0 + 1e-10 if scaling == -1 else 1e3)
+        s.terminate()
+    x, delayed, neg, rank = out[int(g["scaling"])]
+    assert neg == int(g["ref_neg"]) and rank == int(g["ref_rank"])
+    assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-10
+    ref_err = np.abs(g["ref_x"] - g["xstar"]).max()
+    assert np.abs(x - g["xstar"]).max() <= 100 * max(ref_err, 1e-12)
+    assert out[0][2] == neg                                   # inertia does not depend on the scaling
+    assert delayed <= out[0][1]
