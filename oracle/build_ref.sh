@@ -114,9 +114,14 @@ echo "build_ref: wrote $OUT/libgalahad_ref.so and $OUT/ref_driver"
 GSLS_LIB=$HERE/../galahad_amd/libgsls.so
 if [ -f "$GSLS_LIB" ]; then
   mkdir -p $W/mod2
-  python3 $HERE/../integration/patch_sls.py $S/sls/sls.f90 $W/sls_gsls.f90
+  python3 $HERE/../integration/patch_sls.py $S/sls/sls.f90 $W/sls_gsls_0.f90
+  # the reference's default configuration (src/makedefs/packages.default:175, MA86_VERSION = ma86v2) passes sls.f90 and
+  # the MA86 dummy through seds/ma86v2.sed; the C interface's dummy (dum/C/hsl_ma86d_ciface.f90) needs that variant
+  sed -f $REF/seds/ma86v2.sed $W/sls_gsls_0.f90 > $W/sls_gsls.f90
+  sed -f $REF/seds/ma86v2.sed $S/dum/hsl_ma86d.f90 > $W/hsl_ma86d_v2.f90
   $FC $OPT -fPIC -module-dir $W/mod2 -c -o $W/obj2_gsls_iface.o $HERE/../galahad_amd/fortran/gsls_iface.f90
   F2="$OPT -fopenmp -fPIC -module-dir $W/mod2 -I$W/mod2 -I$W/mod"
+  $FC $F2 -c -o $W/obj2_hsl_ma86d_v2.o $W/hsl_ma86d_v2.f90
   $FC $F2 -c -o $W/obj2_sls_gsls.o $W/sls_gsls.f90
   $FC $F2 -o $OUT/sls_gsls_driver $HERE/ref_driver.f90 \
       $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
@@ -132,5 +137,24 @@ if [ -f "$GSLS_LIB" ]; then
   $FC $F2 -o $OUT/trs_gsls_driver $HERE/trs_driver.f90 $W/obj2_trs.o $W/obj2_ir.o \
       $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
       -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
-  echo "build_ref: wrote $OUT/sls_gsls_driver, sbls_gsls_driver, trs_gsls_driver (GALAHAD SLS/SBLS/TRS + gsls backend)"
+  # the C interface of SLS (include/sls.h, src/sls/C/sls_ciface.f90) above the patched facade, and the reference's own C
+  # test of it (src/sls/C/slst.c, compiled where it lies).  galahad_precision.h is staged exactly as the reference's
+  # makefiles do (src/sls/makemaster:149: cp include/galahad_double.h $(OBJ)/galahad_precision.h).
+  mkdir -p $W/cinc
+  cp $REF/include/galahad_double.h $W/cinc/galahad_precision.h
+  for f in common/C/common_ciface sils/C/sils_ciface dum/C/hsl_ma57d_ciface dum/C/hsl_ma77d_ciface \
+           dum/C/hsl_ma86d_ciface dum/C/hsl_ma87d_ciface dum/C/hsl_ma97d_ciface dum/C/hsl_mc64d_ciface \
+           dum/C/hsl_mc68i_ciface dum/C/ssids_ciface ; do
+    $FC $F2 -c -o $W/obj2_$(basename $f).o $S/$f.f90
+  done
+  $FC $F2 -c -o $W/obj2_sls_ciface.o $S/sls/C/sls_ciface.f90
+  gcc -O1 -I$W/cinc -I$REF/include -c -o $W/obj2_slst_c.o $S/sls/C/slst.c
+  gcc -O1 -c -o $W/obj2_wrap.o $HERE/ciface_solver_wrap.c
+  $FC $F2 -o $OUT/slst_c_gsls $W/obj2_slst_c.o $W/obj2_wrap.o $W/obj2_sls_ciface.o $W/obj2_common_ciface.o \
+      $W/obj2_sils_ciface.o $W/obj2_hsl_ma57d_ciface.o $W/obj2_hsl_ma77d_ciface.o $W/obj2_hsl_ma86d_ciface.o \
+      $W/obj2_hsl_ma87d_ciface.o $W/obj2_hsl_ma97d_ciface.o $W/obj2_hsl_mc64d_ciface.o $W/obj2_hsl_mc68i_ciface.o \
+      $W/obj2_ssids_ciface.o $W/obj2_sls_gsls.o $W/obj2_hsl_ma86d_v2.o $W/obj2_gsls_iface.o -Wl,--wrap=sls_initialize \
+      -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' \
+      -lstdc++ -lm -fno-fortran-main 2>$W/link.log || { cat $W/link.log; exit 1; }
+  echo "build_ref: wrote $OUT/sls_gsls_driver, sbls_gsls_driver, trs_gsls_driver, slst_c_gsls (GALAHAD SLS/SBLS/TRS + gsls backend)"
 fi
