@@ -148,13 +148,15 @@ if [ -f "$GSLS_LIB" ]; then
     $FC $F2 -c -o $W/obj2_$(basename $f).o $S/$f.f90
   done
   $FC $F2 -c -o $W/obj2_sls_ciface.o $S/sls/C/sls_ciface.f90
-  gcc -O1 -I$W/cinc -I$REF/include -c -o $W/obj2_slst_c.o $S/sls/C/slst.c
   gcc -O1 -c -o $W/obj2_wrap.o $HERE/ciface_solver_wrap.c
-  $FC $F2 -o $OUT/slst_c_gsls $W/obj2_slst_c.o $W/obj2_wrap.o $W/obj2_sls_ciface.o $W/obj2_common_ciface.o \
+  for t in slst slstf ; do       # C (0-based) and Fortran (1-based) indexing variants of the reference's test
+  gcc -O1 -I$W/cinc -I$REF/include -c -o $W/obj2_slst_c.o $S/sls/C/$t.c
+  $FC $F2 -o $OUT/${t}_c_gsls $W/obj2_slst_c.o $W/obj2_wrap.o $W/obj2_sls_ciface.o $W/obj2_common_ciface.o \
       $W/obj2_sils_ciface.o $W/obj2_hsl_ma57d_ciface.o $W/obj2_hsl_ma77d_ciface.o $W/obj2_hsl_ma86d_ciface.o \
       $W/obj2_hsl_ma87d_ciface.o $W/obj2_hsl_ma97d_ciface.o $W/obj2_hsl_mc64d_ciface.o $W/obj2_hsl_mc68i_ciface.o \
       $W/obj2_ssids_ciface.o $W/obj2_sls_gsls.o $W/obj2_hsl_ma86d_v2.o $W/obj2_gsls_iface.o -Wl,--wrap=sls_initialize \
       -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' \
-      -lstdc++ -lm -fno-fortran-main 2>$W/link.log || { cat $W/link.log; exit 1; }
+      -lstdc++ -lm 2>$W/link.log || { cat $W/link.log; exit 1; }
+  done
   echo "build_ref: wrote $OUT/sls_gsls_driver, sbls_gsls_driver, trs_gsls_driver, slst_c_gsls (GALAHAD SLS/SBLS/TRS + gsls backend)"
 fi

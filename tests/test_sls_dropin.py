@@ -130,3 +130,44 @@ def test_cfg5_full_size_properties():
     x2 = s.solve(m, rhs, c, i)
     assert np.array_equal(x, x2)
     s.terminate()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe", ["slst_c_gsls", "slstf_c_gsls"])
+def test_reference_c_interface_test_with_gsls(exe):
+    """the reference's C interface (include/sls.h, src/sls/C/sls_ciface.f90) compiled above the
+    patched facade, and the reference's OWN C tests of it (src/sls/C/slst.c, slstf.c, compiled where they lie by
+    oracle/build_ref.sh) run with solver "gsls" instead of "sils" (the solver string is substituted at link time,
+    oracle/ciface_solver_wrap.c).  Three storage formats x {solve, solve with refinement, L/D/U part solves}: all ok."""
+    import subprocess
+    path = os.path.join(os.path.dirname(HERE), "oracle", "_ref", exe)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/%s not built" % exe)
+    p = subprocess.run([path], env=dict(os.environ, GSLS_CTEST_SOLVER="gsls"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rows = [ln for ln in p.stdout.splitlines() if ln.strip().startswith(("coordinate", "sparse by rows", "dense"))]
+    assert len(rows) == 3, p.stdout
+    for ln in rows:
+        assert ln.count("ok") == 3 and "fail" not in ln and "status" not in ln, p.stdout
+
+
+SCALED = sorted(glob.glob(os.path.join(HERE, "golden", "scaled_*.npz")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SCALED, ids=[os.path.basename(p)[:-4] for p in SCALED])
+def test_dropin_scaling_controls_through_real_sls(path):
+    """control%scaling = -1 / -2 through the REAL facade (SLS_copy_control_to_gsls in integration/patch_sls.py maps it
+    as the ssids arm does, sls.f90:1405-1413) against the reference run with the same control."""
+    refio = _need_dropin()
+    g = np.load(path)
+    n = int(g["n"])
+    r = refio.run(n, g["row"], g["col"], g["val"], g["rhs"], solver="gsls", perm=g["perm"], nemin=int(g["nemin"]),
+                  pivot_control=1, scaling=int(g["scaling"]))
+    assert (r["status_analyse"], r["status_factorize"], r["status_solve"]) == (0, 0, 0)
+    assert r["negative_eigenvalues"] == int(g["ref_neg"]) and r["rank"] == int(g["ref_rank"])
+    ref_err = np.abs(g["ref_x"] - g["xstar"]).max()
+    assert np.abs(r["x"] - g["xstar"]).max() <= 100 * max(ref_err, 1e-12)
+    plain = refio.run(n, g["row"], g["col"], g["val"], g["rhs"], solver="gsls", perm=g["perm"], nemin=int(g["nemin"]),
+                      pivot_control=1)
+    assert r["delayed"] <= plain["delayed"]
