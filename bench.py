@@ -71,6 +71,8 @@ def parse():
                          "definite, the inertia (n, m, 0) must not change) and report "
                          "their time and how many blocks needed the pivoting fallback (extra field `drift`)")
     ap.add_argument("--drift-decades", type=float, default=2.0, help="width of the drift: x 10^U(0, this)")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo); never a measurement")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     a = ap.parse_args()
@@ -159,7 +161,7 @@ def facade_timings(prob, a, nemin):
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist

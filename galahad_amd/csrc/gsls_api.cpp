@@ -407,7 +407,33 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
     zero[j] = (dj == 0.0) || (dj <= 1e-8 * cmax[j]);
     nzero += zero[j];
   }
-  if (nzero == 0) return GSLS_SUCCESS;
+  // quasi-definite saddle points K = [H A^T; A -E] (interior-point systems with slack or regularisation blocks): a
+  // variable with a NEGATIVE diagonal entry all of whose neighbours have positive ones is a constraint row as well.  As
+  // a pivot of its own, -e_i passes the threshold test only while e_i is large; behind its neighbours its pivot is
+  // -(e_i + a H^-1 a^T) whatever the iteration has made of e_i.  The rule looks at signs only, so the order does not
+  // depend on the values of the first factorization (CQP's E shrinks by many decades between its iterations).
+  std::vector<char> late(n, 0);
+  int nlate = 0;
+  {
+    std::vector<char> negd(n, 0), posd(n, 0), ok(n, 1);
+    for (int j = 0; j < n; ++j)
+      if (!zero[j] && h->diagpos[j] >= 0) {
+        negd[j] = val[h->diagpos[j]] < 0.0;
+        posd[j] = val[h->diagpos[j]] > 0.0;
+      }
+    for (int j = 0; j < n; ++j)
+      for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
+        const int i = h->row[k] - 1;
+        if (i == j || val[k] == 0.0) continue;
+        if (!posd[j]) ok[i] = 0;
+        if (!posd[i]) ok[j] = 0;
+      }
+    for (int j = 0; j < n; ++j) {
+      late[j] = negd[j] && ok[j];
+      nlate += late[j];
+    }
+  }
+  if (nzero == 0 && nlate == 0) return GSLS_SUCCESS;
   const std::vector<int>& pos = h->S.perm;
   // per variable: last position among its neighbours; for zero-diagonal variables also whether any neighbour
   // has a diagonal entry, and the strongest coupling to another zero-diagonal variable
@@ -440,6 +466,10 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
   int moved = 0;
   for (int p2 = 0; p2 < n; ++p2) {
     const int v2 = h->S.invp[p2];
+    if (late[v2]) {
+      if (nbmax[v2] > pos[v2]) { key[pos[v2]] = double(nbmax[v2]) + 0.5; ++moved; }
+      continue;
+    }
     if (!zero[v2] || matched[v2]) continue;
     if (has_nz[v2]) {
       if (nbmax[v2] > pos[v2]) { key[pos[v2]] = double(nbmax[v2]) + 0.5; ++moved; }
@@ -454,6 +484,35 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
       ++moved;
     }
   }
+  // (3) slack variables of an interior-point KKT system [H+D 0 A^T; 0 D_s -I; A -I 0]: a variable whose ONLY neighbour is
+  //     a zero-diagonal one.  Its own entry y_i/s_i runs from huge (active constraint) to ~0 (inactive) over the
+  //     iterations, so as a 1x1 pivot far from its constraint row it fails the threshold test sooner or later; placed
+  //     right in front of that row, in the same supernode, the pair is a 2x2 pivot whenever the 1x1 is refused --
+  //     decided inside one diagonal block, no cross-front repair.  Structural, hence independent of the values.
+  {
+    std::vector<int> deg(n, 0), only(n, -1);
+    for (int j = 0; j < n; ++j)
+      for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
+        const int i = h->row[k] - 1;
+        if (i == j) continue;
+        ++deg[i]; only[i] = j;
+        ++deg[j]; only[j] = i;
+      }
+    std::vector<char> taken(n, 0);
+    for (int v2 = 0; v2 < n; ++v2) {
+      if (zero[v2] || late[v2] || deg[v2] != 1) continue;
+      const int c2 = only[v2];
+      if (!zero[c2] || !has_nz[c2] || taken[c2] || matched[c2]) continue;
+      taken[c2] = 1;
+      const double kc = (key[pos[c2]] != double(pos[c2])) ? key[pos[c2]] : double(pos[c2]);
+      if (pos[v2] == pos[c2] - 1 && kc == double(pos[c2])) continue;     // already adjacent
+      key[pos[v2]] = kc - 0.25;
+      h->partner[v2] = c2;
+      h->partner[c2] = v2;
+      h->force[v2] = 1;
+      ++moved;
+    }
+  }
   if (moved == 0) return GSLS_SUCCESS;
   std::vector<int> idx(n);
   for (int p2 = 0; p2 < n; ++p2) idx[p2] = p2;
@@ -462,7 +521,7 @@ static int refine_order_with_values(Handle* h, const double* val, bool on_device
   for (int newpos = 0; newpos < n; ++newpos) order[h->S.invp[idx[newpos]]] = newpos + 1;
   const int rf = reanalyse(h, order, inform);
   if (rf < 0) return rf;
-  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] %d zero-diagonal variables ordered after their neighbours\n", nzero);
+  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] %d zero-diagonal and %d negative-diagonal constraint variables ordered after their neighbours\n", nzero, nlate);
   return GSLS_SUCCESS;
 }
 
@@ -642,8 +701,43 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       h->tiny_black.insert(h->tiny_black.end(), nodes.begin(), nodes.end());
       std::sort(h->tiny_black.begin(), h->tiny_black.end());
       h->tiny_black.erase(std::unique(h->tiny_black.begin(), h->tiny_black.end()), h->tiny_black.end());
-      if (getenv("GSLS_DEBUG"))
+      if (getenv("GSLS_DEBUG")) {
         fprintf(stderr, "[gsls] pass %d: %d tiny fronts need pivoting (blacklist %zu), repeating\n", pass, st[13], h->tiny_black.size());
+        // what the diagonal looks like now (diagnostic only)
+        const int n = h->S.n;
+        const int64_t nzv = h->ptr[n] - 1;
+        std::vector<double> hv(static_cast<size_t>(nzv));
+        if (hipMemcpy(hv.data(), d_val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+          int nneg = 0, nzer = 0, nnan = 0;
+          double amin = 1e300, amax = 0, omax = 0;
+          for (int j = 0; j < n; ++j) {
+            const double d = h->diagpos[j] >= 0 ? hv[h->diagpos[j]] : 0.0;
+            if (d != d) ++nnan;
+            if (d < 0) ++nneg;
+            if (d == 0) ++nzer; else { amin = std::min(amin, std::fabs(d)); amax = std::max(amax, std::fabs(d)); }
+          }
+          for (int64_t k = 0; k < nzv; ++k) if (hv[k] == hv[k]) omax = std::max(omax, std::fabs(hv[k]));
+          fprintf(stderr, "[gsls]   diagonal: %d negative, %d zero, %d NaN, |d| in [%.3e, %.3e], largest entry %.3e\n", nneg, nzer, nnan, amin, amax, omax);
+          std::vector<double> cm(n, 0.0);
+          for (int j = 0; j < n; ++j)
+            for (int64_t k = h->ptr[j] - 1; k < h->ptr[j + 1] - 1; ++k) {
+              const int i = h->row[k] - 1;
+              if (i == j) continue;
+              cm[i] = std::max(cm[i], std::fabs(hv[k]));
+              cm[j] = std::max(cm[j], std::fabs(hv[k]));
+            }
+          int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int j = 0; j < n; ++j) {
+            const double d = h->diagpos[j] >= 0 ? std::fabs(hv[h->diagpos[j]]) : 0.0;
+            if (d == 0 || cm[j] == 0) continue;
+            const double r = cm[j] / d;          // the multiplier a 1x1 pivot on the ORIGINAL entry would give
+            int b = r <= 1 ? 0 : r <= 10 ? 1 : r <= 100 ? 2 : r <= 1e3 ? 3 : r <= 1e4 ? 4 : r <= 1e6 ? 5 : r <= 1e8 ? 6 : 7;
+            hist[b]++;
+          }
+          fprintf(stderr, "[gsls]   max|offdiag|/|diag| per variable: <=1: %d, <=10: %d, <=100: %d, <=1e3: %d, <=1e4: %d, <=1e6: %d, <=1e8: %d, more: %d\n",
+                  hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+        }
+      }
       if (++tiny_repeats > 4 || st[13] > FAILCAP || h->tiny_black.size() * 10 > size_t(h->S.nnodes)) {
         tiny_off = true;                         // not a pattern for that kernel
         if (++h->tiny_strikes >= 3) h->tiny_ready = false;

@@ -137,6 +137,15 @@ if [ -f "$GSLS_LIB" ]; then
   $FC $F2 -o $OUT/trs_gsls_driver $HERE/trs_driver.f90 $W/obj2_trs.o $W/obj2_ir.o \
       $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
       -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  # BASELINE.json configs[0]: CQP (interior point) -> SBLS -> SLS on QPBAND, above the patched facade (the solver is
+  # chosen by name at run time: the reference's dense 'sytr' arm or 'gsls'); CQP's own dependencies in USE order
+  for f in checkpoint/checkpoint lms/lms scu/scu cro/cro fdc/fdc fit/fit gltr/gltr lpqp/lpqp presolve/presolve \
+           qpp/qpp trans/trans scale/scale qpd/qpd rpd/rpd cqp/cqp ; do
+    $FC $F2 -c -o $W/obj2_q_$(basename $f).o $S/$f.f90
+  done
+  $FC $F2 -o $OUT/cqp_gsls_driver $HERE/cqp_driver.f90 $W/obj2_q_*.o $W/obj2_sbls.o \
+      $W/obj2_sls_gsls.o $W/obj2_hsl_ma86d_v2.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
   # the C interface of SLS (include/sls.h, src/sls/C/sls_ciface.f90) above the patched facade, and the reference's own C
   # test of it (src/sls/C/slst.c, compiled where it lies).  galahad_precision.h is staged exactly as the reference's
   # makefiles do (src/sls/makemaster:149: cp include/galahad_double.h $(OBJ)/galahad_precision.h).

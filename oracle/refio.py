@@ -195,9 +195,55 @@ def run_trs(n, H, c, radius, f=0.0, *, solver="gsls", mdiag=0.0, print_level=0, 
             raise RuntimeError("trs driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
         if print_level:
             print(p.stdout)
+        if os.environ.get("GSLS_DEBUG"):
+            print(p.stderr[-20000:])
         buf = open(pout, "rb").read()
         ints = np.frombuffer(buf, dtype="<i4", count=4)
         dbl = np.frombuffer(buf, dtype="<f8", count=4, offset=16)
         x = np.frombuffer(buf, dtype="<f8", count=n, offset=48).copy()
         return dict(status=int(ints[0]), factorizations=int(ints[1]), obj=float(dbl[0]),
                     multiplier=float(dbl[1]), x_norm=float(dbl[2]), time=float(dbl[3]), x=x)
+
+
+CQP_DROPIN = os.path.join(HERE, "_ref", "cqp_gsls_driver")    # reference CQP + SBLS + patched SLS facade (sytr | gsls)
+
+
+def cqp_available():
+    return os.path.exists(CQP_DROPIN) and os.access(CQP_DROPIN, os.X_OK)
+
+
+def run_cqp(n, m, H, A, g, c_l, c_u, x_l, x_u, *, solver="gsls", print_level=0, timeout=3600):
+    """CQP_solve on min 1/2 x'Hx + g'x s.t. c_l <= Ax <= c_u, x_l <= x <= x_u.  H, A = (row, col, val), 1-based,
+    H lower triangle.  solver: 'sytr' (the reference's dense LAPACK arm) or 'gsls'."""
+    if not cqp_available():
+        raise RuntimeError("oracle/_ref/cqp_gsls_driver not built")
+    with tempfile.TemporaryDirectory(prefix="gsls_cqp_") as d:
+        pin, pout = os.path.join(d, "p.bin"), os.path.join(d, "r.bin")
+        with open(pin, "wb") as f:
+            f.write(struct.pack("<2i", 1129336146, 1))
+            f.write(struct.pack("<6i", n, m, len(H[0]), len(A[0]), 4 if solver == "gsls" else 1, print_level))
+            for (r, c, v) in (H, A):
+                f.write(np.ascontiguousarray(r, dtype=np.int32).tobytes())
+                f.write(np.ascontiguousarray(c, dtype=np.int32).tobytes())
+                f.write(np.ascontiguousarray(v, dtype=np.float64).tobytes())
+            for v in (g, c_l, c_u, x_l, x_u):
+                f.write(np.ascontiguousarray(v, dtype=np.float64).tobytes())
+        env = dict(os.environ)
+        env["OMP_CANCELLATION"] = "true"
+        cmd = "ulimit -s unlimited 2>/dev/null; exec '%s' '%s' '%s'" % (CQP_DROPIN, pin, pout)
+        p = subprocess.run(["bash", "-c", cmd], env=env, capture_output=True, text=True, timeout=timeout)
+        if p.returncode != 0 or not os.path.exists(pout):
+            raise RuntimeError("cqp driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
+        if print_level:
+            print(p.stdout)
+        buf = open(pout, "rb").read()
+        ints = np.frombuffer(buf, dtype="<i4", count=4)
+        reals = np.frombuffer(buf, dtype="<f8", count=7, offset=16)
+        o = 16 + 56
+        x = np.frombuffer(buf, dtype="<f8", count=n, offset=o).copy()
+        y = np.frombuffer(buf, dtype="<f8", count=m, offset=o + 8 * n).copy()
+        z = np.frombuffer(buf, dtype="<f8", count=n, offset=o + 8 * (n + m)).copy()
+        return dict(status=int(ints[0]), iter=int(ints[1]), nfacts=int(ints[2]), obj=float(reals[0]),
+                    primal_infeasibility=float(reals[1]), dual_infeasibility=float(reals[2]),
+                    complementary_slackness=float(reals[3]), time_total=float(reals[4]),
+                    time_factorize=float(reals[5]), time_solve=float(reals[6]), x=x, y=y, z=z)

@@ -170,3 +170,20 @@ def grid3d_27pt_perturbed(nx, ny, nz, seed=20240105, frac=0.10):
     xstar = np.ones(n)
     rhs = sym_matvec(n, row, col, val, xstar)
     return n, (row + 1).astype(np.int32), (col + 1).astype(np.int32), val, rhs, xstar
+
+
+def qpband(N):
+    """examples/QPBAND.SIF / QPBAND.qplib (BASELINE.json configs[0]): min 1/2 x'Hx + g'x, H = tridiag(2, -1),
+    g_i = -i/N, x_i + x_{M+i} >= 1 for i = 1..M = N/2, 0 <= x <= 2.  Returns (n, m, H, A, g, c_l, c_u, x_l, x_u) with
+    1-based COO triples, H lower triangle."""
+    n, m = N, N // 2
+    i = np.arange(1, n + 1, dtype=np.int32)
+    hr = np.r_[i, i[1:]]
+    hc = np.r_[i, i[:-1]]
+    hv = np.r_[np.full(n, 2.0), np.full(n - 1, -1.0)]
+    k = np.arange(1, m + 1, dtype=np.int32)
+    ar = np.r_[k, k]
+    ac = np.r_[k, k + m]
+    av = np.ones(2 * m)
+    g = -np.arange(1, n + 1) / float(N)
+    return (n, m, (hr, hc, hv), (ar, ac, av), g, np.ones(m), np.full(m, 1e20), np.zeros(n), np.full(n, 2.0))

@@ -106,3 +106,43 @@ def test_sbls_cfg3_full_size():
     assert np.abs(r["sol"] - 1.0).max() <= 1e-7
     print("cfg3 through SBLS: factorize median %.3f s, solve median %.3f s" % (
         r["t_factorize_median"], r["t_solve_median"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [5, 10, 100, 2000])
+def test_cqp_qpband_through_sbls_and_gsls(N):
+    """BASELINE.json configs[0]: the reference's interior-point QP solver CQP (src/cqp/cqp.f90, built where it lies with
+    its 14 dependencies above the patched facade) on examples/QPBAND.SIF, every KKT system going
+    CQP -> SBLS_form_and_factorize / SBLS_solve -> SLS('gsls') (cqp.f90:4781-4896).  Checked: CQP's own exit status and
+    residuals, the KKT conditions recomputed here from the returned (x, y, z), and -- small N -- the optimal value
+    against an independent solve (scipy SLSQP).  The comparison run on a reference solver is not available: ssids needs
+    METIS or MC68 (stubs in the reference tree; CQP passes no PERM) and the dense 'sytr' arm fails inside the reference's
+    own SBLS_form_and_factorize with -9 on this problem (seen with the unpatched control flow too)."""
+    from oracle import refio
+    if not refio.cqp_available():
+        pytest.skip("oracle/_ref/cqp_gsls_driver not built")
+    n, m, H, A, g, c_l, c_u, x_l, x_u = P.qpband(N)
+    r = refio.run_cqp(n, m, H, A, g, c_l, c_u, x_l, x_u, solver="gsls")
+    assert r["status"] == 0 and r["iter"] <= 30, r
+    assert r["primal_infeasibility"] <= 1e-8 and r["dual_infeasibility"] <= 1e-5 and r["complementary_slackness"] <= 1e-5
+    x, y, z = r["x"], r["y"], r["z"]
+    Hx = P.sym_matvec(n, H[0] - 1, H[1] - 1, H[2], x)
+    Ax = np.zeros(m)
+    np.add.at(Ax, A[0] - 1, A[2] * x[A[1] - 1])
+    ATy = np.zeros(n)
+    np.add.at(ATy, A[1] - 1, A[2] * y[A[0] - 1])
+    assert np.abs(Hx + g - ATy - z).max() <= 2e-5                       # stationarity (CQP stops at ~7e-6)
+    assert (Ax >= c_l - 1e-8).all() and (x >= x_l - 1e-8).all() and (x <= x_u + 1e-8).all()
+    assert (y >= -1e-8).all() and np.abs(y * (Ax - c_l)).max() <= 1e-4  # multipliers of >= constraints, complementarity
+    assert abs(r["obj"] - (0.5 * x @ Hx + g @ x)) <= 1e-8 * max(1.0, abs(r["obj"]))
+    if N <= 100:
+        from scipy.optimize import minimize, LinearConstraint, Bounds
+        import scipy.sparse as sp
+        Hm = sp.coo_matrix((H[2], (H[0] - 1, H[1] - 1)), shape=(n, n)).toarray()
+        Hm = Hm + Hm.T - np.diag(np.diag(Hm))
+        Am = sp.coo_matrix((A[2], (A[0] - 1, A[1] - 1)), shape=(m, n)).toarray()
+        res = minimize(lambda v: 0.5 * v @ Hm @ v + g @ v, np.ones(n), jac=lambda v: Hm @ v + g, method="SLSQP",
+                       bounds=Bounds(x_l, x_u), constraints=[LinearConstraint(Am, c_l, np.inf)],
+                       options={"ftol": 1e-14, "maxiter": 1000})
+        assert res.success
+        assert abs(res.fun - r["obj"]) <= 1e-5 * max(1.0, abs(res.fun))
