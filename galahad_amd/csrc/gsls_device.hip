@@ -3670,6 +3670,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       // group too big or too deep -- then the children's subtrees are closed (each becomes a group)
       std::vector<int> open(nn, 0), hgt(nn, 0);
       std::vector<char> closed(nn, 0);
+      const int upper_lvl = getenv("GSLS_UPPER_LVL") ? atoi(getenv("GSLS_UPPER_LVL")) : 1024;
       for (int s = 0; s < nn; ++s) {
         if (!waveT[s]) {
           for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci)
@@ -3683,7 +3684,12 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
           sz += open[c];
           h = std::max(h, hgt[c] + 1);
         }
-        if (sz > gmax || h > WSLOT) {
+        // near the top of the tree a level holds few fronts and a wave walking a group serialises them: there a front
+        // only extends a CHAIN (one open child); siblings stay separate groups and run side by side, a stage earlier
+        int nopen = 0;
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) nopen += closed[S.clist[ci]] ? 0 : 1;
+        const bool upper = (S.lvlptr[S.level[s] + 1] - S.lvlptr[S.level[s]]) < upper_lvl;
+        if (sz > gmax || h > WSLOT || (upper && nopen > 1)) {
           for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) closed[S.clist[ci]] = 1;
           sz = 1;
           h = 1;
