@@ -61,6 +61,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
                      int nemin, Symbolic& S, const uint8_t* force_var = nullptr);
 
 // fill-reducing ordering (nested dissection on the graph of A); writes perm[var] = position (0-based)
+void order_amd(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow, std::vector<int>& perm);
 void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow,
                              std::vector<int>& perm);
 

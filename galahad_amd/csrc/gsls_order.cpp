@@ -201,4 +201,124 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
   }
 }
 
+
+// =================================================================================================
+// Approximate minimum degree (gsls_options.ordering = GSLS_ORDER_AMD): the ordering GALAHAD's SLS offers as
+// control%ordering = 1 through HSL MC68 (src/sls/sls.f90:2263-2330; MC68 is a stub in the reference tree), for irregular
+// patterns where level-structure nested dissection finds no small separators.  Quotient-graph elimination in the
+// Amestoy-Davis-Duff scheme: a variable keeps its remaining original neighbours A_i and the elements (eliminated
+// pivots) E_i it belongs to; eliminating p forms the element L_p = A_p U (U_{e in E_p} L_e) \ {p}, absorbs the elements of
+// E_p, and the degree of every i in L_p becomes the approximate external degree
+//      d_i = min( n - k,  d_i + |L_p \ i|,  |A_i \ L_p| + |L_p \ i| + sum_{e in E_i \ p} |L_e \ L_p| )
+// with |L_e \ L_p| obtained for all e at once by the counting pass over L_p (the "w" trick).  Variables that become
+// indistinguishable are not merged (no supervariables) and there is no aggressive absorption: host work that runs once
+// per analyse, O(sum of |L_p| * elements touched).
+// =================================================================================================
+void order_amd(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow, std::vector<int>& perm) {
+  perm.assign(n, -1);
+  if (n == 0) return;
+  std::vector<std::vector<int>> A(n), E(n), L(n);      // L[e]: variables of element e (e = an eliminated pivot)
+  std::vector<int> deg(n), w(n, -1), mark(n, -1);
+  std::vector<char> dead(n, 0), elim(n, 0);
+  for (int i = 0; i < n; ++i) {
+    for (int64_t k = aptr[i]; k < aptr[i + 1]; ++k)
+      if (arow[k] != i) A[i].push_back(arow[k]);
+    std::sort(A[i].begin(), A[i].end());
+    A[i].erase(std::unique(A[i].begin(), A[i].end()), A[i].end());
+    deg[i] = int(A[i].size());
+  }
+  // degree buckets as doubly linked lists
+  std::vector<int> head(n + 1, -1), next(n, -1), prev(n, -1);
+  auto bucket_insert = [&](int i) {
+    const int d = deg[i];
+    next[i] = head[d];
+    prev[i] = -1;
+    if (head[d] >= 0) prev[head[d]] = i;
+    head[d] = i;
+  };
+  auto bucket_remove = [&](int i) {
+    const int d = deg[i];
+    if (prev[i] >= 0) next[prev[i]] = next[i]; else head[d] = next[i];
+    if (next[i] >= 0) prev[next[i]] = prev[i];
+  };
+  for (int i = 0; i < n; ++i) bucket_insert(i);
+  int mindeg = 0;
+  std::vector<int> Lp;
+  for (int k = 0; k < n; ++k) {
+    while (mindeg < n && head[mindeg] < 0) ++mindeg;
+    const int p = head[mindeg];
+    bucket_remove(p);
+    elim[p] = 1;
+    perm[p] = k;
+    const int kp = k;          // (mass elimination below advances k)
+    // ---- the new element ----------------------------------------------------------------------------------
+    Lp.clear();
+    mark[p] = kp;
+    for (int i : A[p])
+      if (!elim[i] && mark[i] != kp) { mark[i] = kp; Lp.push_back(i); }
+    for (int e : E[p]) {
+      if (dead[e]) continue;
+      for (int i : L[e])
+        if (!elim[i] && mark[i] != kp) { mark[i] = kp; Lp.push_back(i); }
+      dead[e] = 1;                       // absorbed into p
+      std::vector<int>().swap(L[e]);
+    }
+    std::vector<int>().swap(A[p]);
+    std::vector<int>().swap(E[p]);
+    // ---- |L_e \ L_p| for every element adjacent to a variable of L_p -------------------------------------------
+    for (int i : Lp)
+      for (int e : E[i]) {
+        if (dead[e]) continue;
+        if (w[e] < 0) w[e] = int(L[e].size());
+        --w[e];
+      }
+    // ---- update the variables of L_p --------------------------------------------------------------------------
+    const int lp = int(Lp.size());
+    for (int i : Lp) {
+      bucket_remove(i);
+      // original neighbours now covered by the element (members of L_p, and p itself) leave A_i
+      size_t o = 0;
+      for (int j : A[i])
+        if (!elim[j] && mark[j] != kp) A[i][o++] = j;
+      A[i].resize(o);
+      // dead elements leave E_i, p joins
+      o = 0;
+      int ext = 0;
+      for (int e : E[i])
+        if (!dead[e]) { E[i][o++] = e; ext += std::max(w[e], 0); }
+      E[i].resize(o);
+      E[i].push_back(p);
+      const int d = std::min(std::min(n - kp - 1, deg[i] + lp - 1), int(A[i].size()) + (lp - 1) + ext);
+      deg[i] = std::max(d, 0);
+    }
+    for (int i : Lp)
+      for (int e : E[i])
+        if (e != p) w[e] = -1;
+    // mass elimination: a variable of L_p with no original neighbour left and no other element is adjacent to exactly
+    // L_p \ {i}: it can follow p at once without any further fill
+    {
+      size_t o = 0;
+      int gone = 0;
+      for (int i : Lp) {
+        if (A[i].empty() && E[i].size() == 1) {
+          elim[i] = 1;
+          perm[i] = ++k;
+          std::vector<int>().swap(E[i]);
+          ++gone;
+        } else {
+          Lp[o++] = i;
+        }
+      }
+      Lp.resize(o);
+      if (gone)
+        for (int i : Lp) deg[i] = std::max(deg[i] - gone, 0);
+    }
+    for (int i : Lp) {
+      bucket_insert(i);
+      mindeg = std::min(mindeg, deg[i]);
+    }
+    L[p] = Lp;
+  }
+}
+
 }  // namespace gsls

@@ -266,6 +266,8 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
   } else {
     if (ordering == GSLS_ORDER_NATURAL)
       std::iota(S.perm.begin(), S.perm.end(), 0);
+    else if (ordering == GSLS_ORDER_AMD)
+      order_amd(n, aptr, arow, S.perm);
     else
       order_nested_dissection(n, aptr, arow, S.perm);
     for (int i = 0; i < n; ++i) S.invp[S.perm[i]] = i;

@@ -226,7 +226,8 @@ class SLS:
         else:
             # ssids would call METIS here (sls.f90:3134); gsls uses its own nested dissection for
             # control%ordering <= 0 (SBLS reaches SLS with 0).  Natural order = PERM identity.
-            self.opts.ordering = 1
+            # control%ordering = 1, 2 (the minimum-degree orderings other solvers get from MC68): built-in AMD
+            self.opts.ordering = 2 if int(control.ordering) in (1, 2) else 1
             self.ORDER = np.arange(1, n + 1, dtype=np.int32)
         ginf = Inform()
         flag = lib.gsls_analyse(self.handle, n, self.PTR.ctypes.data_as(_lib.p_i64),

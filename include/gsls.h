@@ -69,6 +69,7 @@ enum {
 enum {
   GSLS_ORDER_USER = 0,     /* `order` supplied by the caller (ssids ordering=0)            */
   GSLS_ORDER_ND = 1,       /* built-in nested dissection (stands where ssids calls METIS)   */
+  GSLS_ORDER_AMD = 2,      /* approximate minimum degree (SLS control%ordering = 1, MC68)    */
   GSLS_ORDER_NATURAL = 3   /* identity                                                      */
 };
 

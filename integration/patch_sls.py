@@ -34,8 +34,10 @@ ARMS = [
          CALL CPU_time( time ) ; CALL CLOCK_time( clock )
          IF ( PRESENT( PERM ) .OR. mc6168_ordering ) THEN
            data%gsls_options%ordering = 0        ! use data%ORDER as given
+         ELSE IF ( control%ordering == 1 .OR. control%ordering == 2 ) THEN
+           data%gsls_options%ordering = 2        ! built-in approximate minimum degree
          ELSE
-           data%gsls_options%ordering = 1        ! built-in nested dissection (control%ordering <= 0)
+           data%gsls_options%ordering = 1        ! built-in nested dissection (control%ordering <= 0, 3, ...)
          END IF
          IF ( ALLOCATED( data%gsls_ptr ) ) THEN
            IF ( SIZE( data%gsls_ptr ) < matrix%n + 1 ) DEALLOCATE( data%gsls_ptr )
@@ -290,6 +292,7 @@ def main(src, dst):
     k = 0
     shared = refine = scatter = 0
     refine_done = False
+    mc68_done = False
     for ln in lines:
         if re.fullmatch(r"\s*CASE \( 'ssids' \)", ln) and k < len(ARMS):
             out.extend(ARMS[k].rstrip("\n").split("\n"))
@@ -319,6 +322,13 @@ def main(src, dst):
             out.extend(REFINE_ARM.rstrip("\n").split("\n"))
             refine_done = True
             continue
+        # SLS_analyse (:2262-2267): the backend orders by itself -- nested dissection, or AMD when control%ordering asks for
+        # the (approximate) minimum degree orderings that the other solvers get from MC68 (control%ordering = 1, 2)
+        if ln.strip() == "mc6168_ordering = control%ordering > 0 .AND. .NOT. PRESENT( PERM )" and not mc68_done:
+            assert out[-1].strip() == "CASE DEFAULT"
+            out.insert(len(out) - 1, "     CASE ( 'gsls' )")
+            out.insert(len(out) - 1, "       mc6168_ordering = .FALSE.")
+            mc68_done = True
         out.append(ln)
         if ln.strip() == "USE SPRAL_SSIDS":
             out.append("     USE GALAHAD_GSLS_double")
@@ -331,7 +341,7 @@ def main(src, dst):
         if ln.strip() == "END SUBROUTINE SLS_copy_inform_from_ssids":
             out.extend(COPY_ROUTINES.split("\n"))
     assert k == len(ARMS), "expected %d ssids arms, patched %d" % (len(ARMS), k)
-    assert shared == 2 and refine_done and scatter == 2, (shared, refine, refine_done, scatter)
+    assert shared == 2 and refine_done and scatter == 2 and mc68_done, (shared, refine, refine_done, scatter, mc68_done)
     text = "\n".join(out)
     assert "USE GALAHAD_GSLS_double" in text and "TYPE ( gsls_keep ) :: gsls_keep" in text
     open(dst, "w").write(text)
