@@ -171,3 +171,17 @@ def test_dropin_scaling_controls_through_real_sls(path):
     plain = refio.run(n, g["row"], g["col"], g["val"], g["rhs"], solver="gsls", perm=g["perm"], nemin=int(g["nemin"]),
                       pivot_control=1)
     assert r["delayed"] <= plain["delayed"]
+
+
+@pytest.mark.gpu
+def test_dropin_minimum_degree_ordering_through_real_sls():
+    """control%ordering = 1 (AMD) through the real facade: for every other solver SLS would call MC68 -- a stub in the
+    reference tree -- while the gsls arm keeps mc6168_ordering false and the backend orders by itself
+    (integration/patch_sls.py).  Irregular pattern: the ordering must beat the natural order's fill by a wide margin."""
+    refio = _need_dropin()
+    n, row, col, val, rhs, xs = P.random_sparse(3000, 4, 21, spd=True)
+    nat = refio.run(n, row, col, val, rhs, solver="gsls", perm=np.arange(1, n + 1), pivot_control=2)
+    amd = refio.run(n, row, col, val, rhs, solver="gsls", ordering=1, pivot_control=2)
+    assert (amd["status_analyse"], amd["status_factorize"], amd["status_solve"]) == (0, 0, 0)
+    assert amd["entries_in_factors"] <= 0.6 * nat["entries_in_factors"]
+    assert np.abs(amd["x"] - xs).max() <= 1e-9
