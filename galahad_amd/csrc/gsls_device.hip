@@ -826,36 +826,33 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLis
   STAMPW(52);
   if (!t.has_contrib || cm <= 0) return;
   // ---- contribution block: C(i, j) = assembled(i, j) - sum_k (L D)(i, k) L(j, k), rows i >= j below the pivots ------
+  // The rows below the pivots go to LDS (over the part of the triangle that held the pivot columns: those are in
+  // registers / written out), then a lane per ENTRY of the block forms its sum: cm (cm + 1) / 2 entries share the 64 lanes
+  // instead of cm columns x NC broadcasts for the few lanes that hold contribution rows.
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  double ldv[NC];
+  if (lane >= n && lane < m) {
+    double* ur = Fr + (lane - n) * n;
 #pragma unroll
-  for (int k = 0; k < NC; ++k) ldv[k] = (k < n) ? v[k] * ps[k] : 0.0;
+    for (int k = 0; k < NC; ++k)
+      if (k < n) ur[k] = v[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  const int nent = (cm * (cm + 1)) >> 1;
   double* Cb = C + t.coff;
-  for (int j0 = 0; j0 < cm; j0 += 8) {
-    double cold[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = j0 + q, c = n + j;
-      cold[q] = (j < cm && lane >= c && lane < m) ? Fr[c * m - ((c * (c + 1)) >> 1) + lane] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = j0 + q;
-      if (j < cm) {                        // uniform
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-          if (NC > 32 && k >= 32 && k >= n) continue;
-          acc = fma(ldv[k], readlane_f64(v[k], n + j), acc);
-        }
-        cold[q] -= acc;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = j0 + q;
-      if (j < cm && lane >= n + j && lane < m) Cb[int64_t(j) * cm + (lane - n)] = cold[q];
-    }
+  for (int e0 = 0; e0 < nent; e0 += 64) {
+    const int e = min(e0 + lane, nent - 1);
+    int i = int((sqrtf(float(8 * e + 1)) - 1.0f) * 0.5f);
+    i += (((i + 1) * (i + 2)) >> 1 <= e) ? 1 : 0;
+    i -= ((i * (i + 1)) >> 1 > e) ? 1 : 0;
+    const int j = e - ((i * (i + 1)) >> 1);
+    const double* ui = Fr + i * n;
+    const double* uj = Fr + j * n;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < n; ++k) acc = fma(ui[k] * ps[k], uj[k], acc);
+    const int c = n + j;
+    const double base = Fr[c * m - ((c * (c + 1)) >> 1) + n + i];
+    if (e0 + lane < nent) Cb[int64_t(j) * cm + i] = base - acc;
   }
 }
 
