@@ -658,7 +658,7 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 // that front on the workgroup path (which has the pivoting fallbacks).  A front with a hinted 2x2 pivot fails at once.
 // =================================================================================================
 constexpr int TINY_N = 64;
-constexpr int TINY_CLASSES = 5;                     // unrolled for 24, 28, 32 and 48 columns; up to 64: k_front_lds
+constexpr int TINY_CLASSES = 5;                     // unrolled for 24, 28, 32 and 48 columns; up to 64: k_front_blk
 static inline int tiny_class(int n) { return n <= 24 ? 0 : n <= 28 ? 1 : n <= 32 ? 2 : n <= 48 ? 3 : 4; }
 struct TinyFrontTask {
   int32_t n, m, ld, sptr;
@@ -3143,17 +3143,22 @@ k_wpack(const WTask* __restrict__ tasks, const WPack* __restrict__ packs, int nt
   }
 }
 
-// The same front kernel with the matrix left in LDS and every loop rolled: ~2 KB of code instead of 28-80 KB.  On a
-// level with a handful of fronts the unrolled kernels spend their time fetching instructions (one cold pass through
-// the whole body per launch); this one is for those levels, and for fronts of 49..64 columns on any level.
+// The same front kernel BLOCKED through LDS: the front stays in its LDS triangle, four pivot columns at a time are taken
+// into registers (lane = row), factorized there exactly as k_front_wave does it (given order, every pivot and multiplier
+// tested, v_readlane broadcasts -- but only inside the 4-column panel), written out, and the rank-4 update of the
+// trailing triangle is done with a lane per ENTRY: all 64 lanes work whatever the front's height, nothing is computed
+// above the diagonal, and the loops are rolled -- one instantiation of ~4 KB serves every front of up to 64 columns
+// (no width classes, no cold pass through tens of KB of unrolled code on the levels with a handful of fronts).
+// After the last panel the trailing triangle IS the contribution block.
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB)
-k_front_lds(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLists g,
+k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLists g,
             const int64_t* __restrict__ asrc, const int32_t* __restrict__ aloc,
             const double* __restrict__ val, double* __restrict__ L, double* __restrict__ D, double* __restrict__ C,
             int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
             const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u,
             double* __restrict__ Lf, double* __restrict__ Lbk, int tri) {
+  typedef double double2_t __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) double fsh[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
@@ -3161,7 +3166,9 @@ k_front_lds(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
   const TinyFrontTask t = tasks[ti];
   if (tinyskip[t.node]) return;
   const int n = t.n, m = t.m, cm = m - n;
-  double* Fr = fsh + wave * tri;
+  double* Fr = fsh + wave * (tri + 512);        // the triangle, then the panel scratch: L[row][4], (L D)[row][4]
+  double2_t* P = reinterpret_cast<double2_t*>(Fr + tri);
+  double2_t* PD = P + 128;
   front_assemble(t, Fr, lane, g, asrc, aloc, val, C);
   const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
   const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
@@ -3169,39 +3176,109 @@ k_front_lds(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
   int nneg = 0;
   double myd0 = 0.0;
   const bool in = lane < m;
-  for (int j = 0; j < n; ++j) {
-    const int oj = j * m - ((j * (j + 1)) >> 1);
-    const double cj = (in && lane >= j) ? Fr[oj + lane] : 0.0;
-    const double d = readlane_f64(cj, j);
-    if (!(fabs(d) >= small)) bad = true;
-    if (d < 0.0) ++nneg;
-    double rd = __builtin_amdgcn_rcp(d);
-    rd = fma(fma(-d, rd, 1.0), rd, rd);
-    rd = fma(fma(-d, rd, 1.0), rd, rd);
-    const double own = cj * rd;
-    if (in && lane > j && !(fabs(own) <= inv_u)) bad = true;
-    int k = j + 1;
-    for (; k + 3 < m; k += 4) {          // four columns' reads in flight, then their writes
-      double f[4], l[4];
-      int o[4];
+  // entry e = lane + 64 p of a lower triangle stored row by row (independent of its order): row i, column j
+  auto decode = [](int e, int& i, int& j) {
+    i = int((sqrtf(float(8 * e + 1)) - 1.0f) * 0.5f);
+    i += (((i + 1) * (i + 2)) >> 1 <= e) ? 1 : 0;
+    i -= ((i * (i + 1)) >> 1 > e) ? 1 : 0;
+    j = e - ((i * (i + 1)) >> 1);
+  };
+  const bool images = Lf && t.lfoff >= 0;
+  double2_t* fimg = reinterpret_cast<double2_t*>(Lf + (images ? t.lfoff : 0));
+  double* bimg = Lbk + (images ? t.lboff : 0);
+  double* Lb = L + t.loff;
+  for (int c0 = 0; c0 < n; c0 += 4) {
+    const int w = min(4, n - c0);
+    // ---- the panel: columns c0 .. c0+w-1, row `lane` -------------------------------------------------------
+    double a[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = k + q;
-        o[q] = kk * m - ((kk * (kk + 1)) >> 1) + lane;
-        l[q] = readlane_f64(cj, kk);
-        f[q] = (in && lane >= kk) ? Fr[o[q]] : 0.0;
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + q;
+      a[q] = (q < w && in && lane >= c) ? Fr[c * m - ((c * (c + 1)) >> 1) + lane] : 0.0;
+    }
+    double dq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < w) {                        // uniform
+        const int c = c0 + q;
+        const double d = readlane_f64(a[q], c);
+        if (!(fabs(d) >= small)) bad = true;
+        if (d < 0.0) ++nneg;
+        double rd = __builtin_amdgcn_rcp(d);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        const double um = a[q];
+        const double own = um * rd;
+        if (in && lane > c && !(fabs(own) <= inv_u)) bad = true;
+#pragma unroll
+        for (int q2 = q + 1; q2 < 4; ++q2)
+          if (q2 < w) a[q2] = fma(-own, readlane_f64(um, c0 + q2), a[q2]);
+        a[q] = (lane == c) ? 1.0 : own;
+        if (lane == c) myd0 = rd;
+        dq[q] = d;
+      }
+    }
+    // ---- the panel out: images (or rectangle), and scratch for the trailing update ------------------------------
+    if (images) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = c0 + 2 * h, j2 = k >> 1, r0 = k + 1;
+        if (k < n && lane >= r0 && in) {
+          double2_t e;
+          e.x = a[2 * h];
+          e.y = (lane > r0 && r0 < n) ? a[2 * h + 1] : 0.0;
+          fimg[wf_pair_off(j2, m) + lane - r0] = e;
+        }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (in && lane >= k + q) Fr[o[q]] = fma(-own, l[q], f[q]);
+      for (int q = 0; q < 4; ++q) {
+        const int k = c0 + q;
+        if (q < w && in && lane > k) bimg[2 * (wb_pair_off(lane >> 1, n) + k) + (lane & 1)] = a[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = c0 + q;
+        if (q < w && in && lane >= k) Lb[int64_t(k) * t.ld + lane] = a[q];
+      }
     }
-    for (; k < m; ++k) {
-      const int o = k * m - ((k * (k + 1)) >> 1) + lane;
-      const double l = readlane_f64(cj, k);
-      if (in && lane >= k) Fr[o] = fma(-own, l, Fr[o]);
+    const int tb = c0 + w, mt = m - tb;            // the trailing triangle: rows / columns tb .. m-1
+    if (mt <= 0) break;
+    if (in) {                                        // L and L D of the panel, row by row
+      P[2 * lane] = double2_t{a[0], a[1]};
+      P[2 * lane + 1] = double2_t{a[2], a[3]};
+      PD[2 * lane] = double2_t{a[0] * dq[0], a[1] * dq[1]};
+      PD[2 * lane + 1] = double2_t{a[2] * dq[2], a[3] * dq[3]};
     }
-    if (in && lane > j) Fr[oj + lane] = own;
-    if (lane == j) myd0 = rd;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // ---- F(i, c) -= sum_q L(i, c0+q) (L D)(c, c0+q) over the trailing triangle: a lane per 2 x 2 TILE of entries
+    //      (rows i, i+1 x columns c, c+1: four panel rows read for four entries)
+    const int T = (mt + 1) >> 1, ntile = (T * (T + 1)) >> 1;
+    for (int e0 = 0; e0 < ntile; e0 += 64) {
+      int I, J;
+      decode(min(e0 + lane, ntile - 1), I, J);
+      const bool on = e0 + lane < ntile;
+      const int i = tb + 2 * I, c = tb + 2 * J;
+      const bool r1 = i + 1 < m;                     // second row exists
+      const bool v01 = I > J;                        // (i, c+1) lies below the diagonal
+      const int ib = r1 ? i + 1 : i, cb = (c + 1 < m) ? c + 1 : c;
+      const double2_t a0 = P[2 * i], a1 = P[2 * i + 1], b0 = P[2 * ib], b1 = P[2 * ib + 1];
+      const double2_t x0 = PD[2 * c], x1 = PD[2 * c + 1], y0 = PD[2 * cb], y1 = PD[2 * cb + 1];
+      const int oc = c * m - ((c * (c + 1)) >> 1), od = cb * m - ((cb * (cb + 1)) >> 1);
+      const int o00 = oc + i, o10 = oc + ib, o01 = v01 ? od + i : o00, o11 = od + ib;
+      double f00 = Fr[o00], f10 = Fr[o10], f01 = Fr[o01], f11 = Fr[o11];
+      f00 = fma(-a0.x, x0.x, f00); f00 = fma(-a0.y, x0.y, f00); f00 = fma(-a1.x, x1.x, f00); f00 = fma(-a1.y, x1.y, f00);
+      f10 = fma(-b0.x, x0.x, f10); f10 = fma(-b0.y, x0.y, f10); f10 = fma(-b1.x, x1.x, f10); f10 = fma(-b1.y, x1.y, f10);
+      f01 = fma(-a0.x, y0.x, f01); f01 = fma(-a0.y, y0.y, f01); f01 = fma(-a1.x, y1.x, f01); f01 = fma(-a1.y, y1.y, f01);
+      f11 = fma(-b0.x, y0.x, f11); f11 = fma(-b0.y, y0.y, f11); f11 = fma(-b1.x, y1.x, f11); f11 = fma(-b1.y, y1.y, f11);
+      if (on) {
+        Fr[o00] = f00;
+        if (r1) Fr[o10] = f10;
+        if (v01) Fr[o01] = f01;
+        if (r1) Fr[o11] = f11;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   }
   if (__ballot(bad) != 0ull) {
     if (lane == 0) {
@@ -3210,21 +3287,6 @@ k_front_lds(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
       fastok[t.iblk] = 0;
     }
     return;
-  }
-  if (Lf && t.lfoff >= 0) {
-    double* f = Lf + t.lfoff;
-    double* bk = Lbk + t.lboff;
-    for (int k = 0; k < n; ++k)
-      if (in && lane > k) {
-        const double v = Fr[k * m - ((k * (k + 1)) >> 1) + lane];
-        const int j = k >> 1;
-        f[2 * (wf_pair_off(j, m) + lane - (2 * j + 1)) + (k & 1)] = v;
-        bk[2 * (wb_pair_off(lane >> 1, n) + k) + (lane & 1)] = v;
-      }
-  } else {
-    double* Lb = L + t.loff;
-    for (int k = 0; k < n; ++k)
-      if (in && lane >= k) Lb[int64_t(k) * t.ld + lane] = (lane == k) ? 1.0 : Fr[k * m - ((k * (k + 1)) >> 1) + lane];
   }
   if (lane < n) {
     D[2 * int64_t(t.sptr + lane)] = myd0;
@@ -3237,9 +3299,12 @@ k_front_lds(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
   }
   if (!t.has_contrib || cm <= 0) return;
   double* Cb = C + t.coff;
-  for (int j = 0; j < cm; ++j) {
-    const int c = n + j;
-    if (in && lane >= c) Cb[int64_t(j) * cm + (lane - n)] = Fr[c * m - ((c * (c + 1)) >> 1) + lane];
+  const int nent = (cm * (cm + 1)) >> 1;
+  for (int e0 = 0; e0 < nent; e0 += 64) {
+    int i2, j2;
+    decode(min(e0 + lane, nent - 1), i2, j2);
+    const int c = n + j2;
+    if (e0 + lane < nent) Cb[int64_t(j2) * cm + i2] = Fr[c * m - ((c * (c + 1)) >> 1) + n + i2];
   }
 }
 
@@ -3388,6 +3453,12 @@ void dev_free(DeviceFactor& F) {
 
 static hipError_t allow_big_lds() {
   const int big = 160 * 1024 - 512;
+  // the wave-per-front kernels: four packed triangles of up to 64 x 64 (+ panel scratch) per workgroup
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_blk<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<24, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<28, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<48, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
@@ -4089,6 +4160,16 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
       const GatherLists gl{F.gdst, F.gbeg, F.gsrc};
       // one launch per width class on a wide level; on a narrow one (latency, not throughput) a single launch of
       // the widest class present.  Classes with few fronts ride with the next wider one.
+      static const int blk_mode = getenv("GSLS_FRONT_BLK") ? atoi(getenv("GSLS_FRONT_BLK")) : 0;
+      if (blk_mode == 1 || (blk_mode == 2 && lp.tf_cnt <= 2048)) {      // every width in one launch of the blocked kernel
+        int maxm = 0;
+        for (int cls = 0; cls < TINY_CLASSES; ++cls) maxm = std::max(maxm, lp.tf_cls_maxm[cls]);
+        const int tri = (maxm * (maxm + 1) / 2 + 1) & ~1, cnt = lp.tf_cnt;
+        const TinyFrontTask* tf = static_cast<const TinyFrontTask*>(F.tftasks) + lp.tf_begin;
+        hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, tf, cnt, gl,
+                           F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail,
+                           small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri);
+      } else {
       int beg = lp.tf_begin, cnt = 0, maxm = 0;
       static const int narrow_max = getenv("GSLS_NARROW_MAX") ? atoi(getenv("GSLS_NARROW_MAX")) : 2048;
       const bool narrow = lp.tf_cnt <= narrow_max;
@@ -4116,11 +4197,12 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
             hipLaunchKernelGGL((k_front_wave<48, 2>), dim3((cnt + 1) / 2), dim3(128), size_t(2) * tri * 8, st, GSLS_FW_ARGS);
             break;
           default:
-            hipLaunchKernelGGL((k_front_lds<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
+            hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, GSLS_FW_ARGS);
         }
 #undef GSLS_FW_ARGS
         beg += cnt;
         cnt = maxm = 0;
+      }
       }
     }
     const int nsteps = int(lp.panel_cnt.size() / 2);
