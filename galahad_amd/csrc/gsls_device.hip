@@ -3458,7 +3458,6 @@ static hipError_t allow_big_lds() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<24, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<28, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<48, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
@@ -4193,10 +4192,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
           case 2:
             hipLaunchKernelGGL((k_front_wave<32, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
             break;
-          case 3:
-            hipLaunchKernelGGL((k_front_wave<48, 2>), dim3((cnt + 1) / 2), dim3(128), size_t(2) * tri * 8, st, GSLS_FW_ARGS);
-            break;
-          default:
+          default:      // more than 32 columns: the blocked kernel (an unrolled 48-column body is 64 KB of code)
             hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, GSLS_FW_ARGS);
         }
 #undef GSLS_FW_ARGS
