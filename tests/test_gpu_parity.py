@@ -704,3 +704,58 @@ def test_reference_scalings(path):
     assert np.abs(x - g["xstar"]).max() <= 100 * max(ref_err, 1e-12)
     assert out[0][2] == neg                                   # inertia does not depend on the scaling
     assert delayed <= out[0][1]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 48, 49, 63, 64, 65, 129])
+@pytest.mark.parametrize("kind", ["spd", "indef"])
+def test_edge_sizes_dense_single_front(n, kind):
+    """one dense front of exactly n columns around every boundary of the kernels' tiers (32 / 48 / 64 columns and rows:
+    wave-per-front unrolled, blocked LDS, workgroup kernels; wave tier of the solves up to 64 rows), first factorization
+    and refactorization, against numpy's dense solve."""
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    rng = np.random.default_rng(100 * n + (kind == "spd"))
+    B = rng.uniform(-1, 1, (n, n))
+    A = B @ B.T / n + np.eye(n) if kind == "spd" else (B + B.T) / 2 + np.diag(np.where(np.arange(n) % 2 == 0, 3.0, -3.0))
+    r, c = np.tril_indices(n)
+    row, col, val = (r + 1).astype(np.int32), (c + 1).astype(np.int32), A[r, c]
+    xs = rng.uniform(-1, 1, n)
+    rhs = A @ xs
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s, ctl, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", ctl, i)
+    ctl.pivot_control = 2 if kind == "spd" else 1
+    ctl.max_iterative_refinements = 0
+    s.analyse(m, ctl, i, PERM=np.arange(1, n + 1))
+    assert i.status == 0
+    xd = np.linalg.solve(A, rhs)
+    for rep in range(3):                       # first factorization, then the learned / refactorization path twice
+        s.factorize(m, ctl, i)
+        assert i.status == 0, (rep, i.gsls_inform)
+        assert i.rank == n
+        assert i.negative_eigenvalues == int((np.linalg.eigvalsh(A) < 0).sum())
+        x = s.solve(m, rhs, ctl, i)
+        assert np.abs(x - xd).max() <= 1e-9 * max(1.0, np.abs(xd).max()), rep
+    s.terminate()
+
+
+def test_empty_system():
+    """n = 0: SLS refuses it as the reference does (GALAHAD_error_restrictions, sls.f90:2217-2222); at the ABI every call
+    is a no-op that succeeds (ssids.f90:256-262, 1180-1183)"""
+    import ctypes as C
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    from galahad_amd._lib import Inform, Options, lib
+    m = SMT(0, "COORDINATE", row=np.zeros(0, np.int32), col=np.zeros(0, np.int32), val=np.zeros(0))
+    s, ctl, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", ctl, i)
+    s.analyse(m, ctl, i)
+    assert i.status == -3
+    s.terminate()
+    h = C.c_void_p()
+    assert lib.gsls_create(C.byref(h)) == 0
+    o, inf = Options(), Inform()
+    lib.gsls_default_options(C.byref(o))
+    ptr = np.ones(1, dtype=np.int64)
+    assert lib.gsls_analyse(h, 0, ptr.ctypes.data_as(C.POINTER(C.c_int64)), None, None, C.byref(o), C.byref(inf)) == 0
+    assert lib.gsls_factor(h, 0, None, None, C.byref(o), C.byref(inf)) == 0
+    assert lib.gsls_solve(h, 0, 1, None, 0, C.byref(o), C.byref(inf)) == 0
+    lib.gsls_destroy(C.byref(h))
