@@ -808,6 +808,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       if (moved || any2) {
         e = hipMemcpy(F.hint, hints.data(), size_t(n), hipMemcpyHostToDevice);
         if (e != hipSuccess) return fail_hip(h, inform, e);
+        F.any_hint = any2;
       }
       if (moved) continue;     // factorize once more in the learned order
     }

@@ -729,7 +729,7 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLis
              const double* __restrict__ val, double* __restrict__ L, double* __restrict__ D, double* __restrict__ C,
              int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
              const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u,
-             double* __restrict__ Lf, double* __restrict__ Lbk, int tri) {
+             double* __restrict__ Lf, double* __restrict__ Lbk, int tri, int skip_hinted) {
   extern __shared__ __attribute__((aligned(16))) double fsh[];
   __shared__ double psh[WPB][NC];     // per wave: the pivots d_k (for L*D)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -740,6 +740,11 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLis
   const int n = t.n, m = t.m, cm = m - n;
   double* Fr = fsh + wave * tri;     // column c (rows c..m-1) at Fr[c*m - c(c+1)/2 + r]
   double* ps = psh[wave];
+  // 1x1 pivots only (a second code path per pivot would double a fully unrolled body): a front with a hinted 2x2 pivot
+  // is left to k_front_blk (launched behind this kernel when the handle holds hints), or reported
+  const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
+  const bool hinted = (__ballot(h2) != 0ull);
+  if (hinted && skip_hinted) return;
   STAMPW(49);
   front_assemble(t, Fr, lane, g, asrc, aloc, val, C);
   STAMPW(50);
@@ -749,8 +754,7 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLis
 #pragma unroll
   for (int k = 0; k < NC; ++k)
     v[k] = (lane < m && k < n && lane >= k) ? Fr[k * m - ((k * (k + 1)) >> 1) + lane] : 0.0;
-  const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
-  bool bad = (__ballot(h2) != 0ull);   // 1x1 pivots only (a second code path per pivot would double a fully unrolled body)
+  bool bad = hinted;
   int nneg = 0;
   double myd0 = 0.0;                   // lane j: inverse of pivot j
 #pragma unroll
@@ -3157,7 +3161,7 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
             const double* __restrict__ val, double* __restrict__ L, double* __restrict__ D, double* __restrict__ C,
             int32_t* __restrict__ stat, int32_t* __restrict__ fastok, const uint8_t* __restrict__ hint,
             const uint8_t* __restrict__ tinyskip, int32_t* __restrict__ tinyfail, double small, double u,
-            double* __restrict__ Lf, double* __restrict__ Lbk, int tri) {
+            double* __restrict__ Lf, double* __restrict__ Lbk, int tri, int mode) {
   typedef double double2_t __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) double fsh[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3166,15 +3170,19 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
   const TinyFrontTask t = tasks[ti];
   if (tinyskip[t.node]) return;
   const int n = t.n, m = t.m, cm = m - n;
+  // learned 2x2 pivots: bit c = columns (c, c+1) are eliminated together
+  const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
+  const unsigned long long hm = __ballot(h2);
+  // mode 1: the pass behind the unrolled kernels -- only the fronts of at most 32 columns they left alone (hinted ones)
+  if (mode == 1 && (n > 32 || hm == 0ull)) return;
   double* Fr = fsh + wave * (tri + 512);        // the triangle, then the panel scratch: L[row][4], (L D)[row][4]
   double2_t* P = reinterpret_cast<double2_t*>(Fr + tri);
   double2_t* PD = P + 128;
   front_assemble(t, Fr, lane, g, asrc, aloc, val, C);
   const double inv_u = (u > 0.0) ? 1.0 / u : INFINITY;
-  const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
-  bool bad = (__ballot(h2) != 0ull);
-  int nneg = 0;
-  double myd0 = 0.0;
+  bool bad = false;
+  int nneg = 0, ntwo = 0;
+  double myd0 = 0.0, myd1 = 0.0;                // lane c: D entries of pivot c (inverted; 2x2: [d11, d21], [inf, d22])
   const bool in = lane < m;
   // entry e = lane + 64 p of a lower triangle stored row by row (independent of its order): row i, column j
   auto decode = [](int e, int& i, int& j) {
@@ -3184,71 +3192,100 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
     j = e - ((i * (i + 1)) >> 1);
   };
   const bool images = Lf && t.lfoff >= 0;
-  double2_t* fimg = reinterpret_cast<double2_t*>(Lf + (images ? t.lfoff : 0));
+  double* fimg = Lf + (images ? t.lfoff : 0);
   double* bimg = Lbk + (images ? t.lboff : 0);
   double* Lb = L + t.loff;
-  for (int c0 = 0; c0 < n; c0 += 4) {
-    const int w = min(4, n - c0);
+  int w = 0;
+  for (int c0 = 0; c0 < n; c0 += w) {
+    w = min(4, n - c0);
+    if (w == 4 && ((hm >> (c0 + 3)) & 1ull)) w = 3;          // a 2x2 pivot must not straddle two panels
     // ---- the panel: columns c0 .. c0+w-1, row `lane` -------------------------------------------------------
-    double a[4];
+    double a[4], um[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = c0 + q;
       a[q] = (q < w && in && lane >= c) ? Fr[c * m - ((c * (c + 1)) >> 1) + lane] : 0.0;
+      um[q] = 0.0;
     }
-    double dq[4] = {0.0, 0.0, 0.0, 0.0};
+    bool second = false;                // column q is the second of a 2x2 pivot (done with the first)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q < w) {                        // uniform
-        const int c = c0 + q;
-        const double d = readlane_f64(a[q], c);
-        if (!(fabs(d) >= small)) bad = true;
-        if (d < 0.0) ++nneg;
-        double rd = __builtin_amdgcn_rcp(d);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        const double um = a[q];
-        const double own = um * rd;
-        if (in && lane > c && !(fabs(own) <= inv_u)) bad = true;
+      if (q >= w) continue;             // uniform
+      if (second) { second = false; continue; }
+      const int c = c0 + q;
+      const bool want2 = ((hm >> c) & 1ull) != 0ull;
+      if (want2 && q + 1 >= w) bad = true;             // (a hint on the last column of the front: no partner)
+      if (want2 && q + 1 < w && q < 3) {
+        const double a11 = readlane_f64(a[q], c), a21 = readlane_f64(a[q], c + 1);
+        const double a22 = readlane_f64(a[q < 3 ? q + 1 : 3], c + 1);
+        // a hinted pair was chosen by one of the pivoting kernels before: accepted unless its determinant cancels
+        // (test_2x2 of ldlt_tpp.cxx:99-118); the multipliers are tested like every other pivot's
+        const double maxpiv = fmax(fabs(a11), fmax(fabs(a21), fabs(a22)));
+        if (!(maxpiv >= small)) bad = true;
+        const double detscale = 1.0 / maxpiv;
+        const double detpiv0 = (a11 * detscale) * a22, detpiv1 = (a21 * detscale) * a21;
+        const double detpiv = detpiv0 - detpiv1;
+        if (!(fabs(detpiv) >= fmax(small, fmax(fabs(detpiv0 / 2), fabs(detpiv1 / 2))))) bad = true;
+        const double d11 = (a22 * detscale) / detpiv, d22 = (a11 * detscale) / detpiv;
+        const double d21 = (-a21 * detscale) / detpiv;
+        const double u1 = a[q], u2 = a[q < 3 ? q + 1 : 3];
+        const double own1 = d11 * u1 + d21 * u2, own2 = d21 * u1 + d22 * u2;
+        if (in && lane > c + 1 && !(fabs(own1) <= inv_u && fabs(own2) <= inv_u)) bad = true;
 #pragma unroll
-        for (int q2 = q + 1; q2 < 4; ++q2)
-          if (q2 < w) a[q2] = fma(-own, readlane_f64(um, c0 + q2), a[q2]);
-        a[q] = (lane == c) ? 1.0 : own;
-        if (lane == c) myd0 = rd;
-        dq[q] = d;
+        for (int q2 = 2; q2 < 4; ++q2)
+          if (q2 > q + 1 && q2 < w)
+            a[q2] = fma(-own1, readlane_f64(u1, c0 + q2), fma(-own2, readlane_f64(u2, c0 + q2), a[q2]));
+        um[q] = u1;
+        um[q < 3 ? q + 1 : 3] = u2;
+        a[q] = (lane == c) ? 1.0 : ((lane == c + 1) ? 0.0 : own1);
+        a[q < 3 ? q + 1 : 3] = (lane == c + 1) ? 1.0 : own2;
+        if (lane == c) { myd0 = d11; myd1 = d21; }
+        if (lane == c + 1) { myd0 = INFINITY; myd1 = d22; }
+        const double det = a11 * a22 - a21 * a21;
+        if (det < 0.0) nneg += 1;
+        else if (a11 + a22 < 0.0) nneg += 2;
+        ++ntwo;
+        second = true;
+        continue;
       }
+      const double d = readlane_f64(a[q], c);
+      if (!(fabs(d) >= small)) bad = true;
+      if (d < 0.0) ++nneg;
+      double rd = __builtin_amdgcn_rcp(d);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      um[q] = a[q];
+      const double own = um[q] * rd;
+      if (in && lane > c && !(fabs(own) <= inv_u)) bad = true;
+#pragma unroll
+      for (int q2 = q + 1; q2 < 4; ++q2)
+        if (q2 < w) a[q2] = fma(-own, readlane_f64(um[q], c0 + q2), a[q2]);
+      a[q] = (lane == c) ? 1.0 : own;
+      if (lane == c) { myd0 = rd; myd1 = 0.0; }
     }
     // ---- the panel out: images (or rectangle), and scratch for the trailing update ------------------------------
-    if (images) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = c0 + 2 * h, j2 = k >> 1, r0 = k + 1;
-        if (k < n && lane >= r0 && in) {
-          double2_t e;
-          e.x = a[2 * h];
-          e.y = (lane > r0 && r0 < n) ? a[2 * h + 1] : 0.0;
-          fimg[wf_pair_off(j2, m) + lane - r0] = e;
+    for (int q = 0; q < 4; ++q) {
+      const int k = c0 + q;
+      if (q < w) {                      // uniform
+        if (images) {
+          if (in && lane > k) {
+            const int j2 = k >> 1;
+            fimg[2 * (wf_pair_off(j2, m) + lane - (2 * j2 + 1)) + (k & 1)] = a[q];
+            bimg[2 * (wb_pair_off(lane >> 1, n) + k) + (lane & 1)] = a[q];
+          }
+        } else if (in && lane >= k) {
+          Lb[int64_t(k) * t.ld + lane] = a[q];
         }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = c0 + q;
-        if (q < w && in && lane > k) bimg[2 * (wb_pair_off(lane >> 1, n) + k) + (lane & 1)] = a[q];
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = c0 + q;
-        if (q < w && in && lane >= k) Lb[int64_t(k) * t.ld + lane] = a[q];
       }
     }
     const int tb = c0 + w, mt = m - tb;            // the trailing triangle: rows / columns tb .. m-1
     if (mt <= 0) break;
-    if (in) {                                        // L and L D of the panel, row by row
+    if (in) {                                        // L and L D (= the columns before they were scaled) of the panel
       P[2 * lane] = double2_t{a[0], a[1]};
       P[2 * lane + 1] = double2_t{a[2], a[3]};
-      PD[2 * lane] = double2_t{a[0] * dq[0], a[1] * dq[1]};
-      PD[2 * lane + 1] = double2_t{a[2] * dq[2], a[3] * dq[3]};
+      PD[2 * lane] = double2_t{um[0], um[1]};
+      PD[2 * lane + 1] = double2_t{um[2], um[3]};
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     // ---- F(i, c) -= sum_q L(i, c0+q) (L D)(c, c0+q) over the trailing triangle: a lane per 2 x 2 TILE of entries
@@ -3290,12 +3327,13 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
   }
   if (lane < n) {
     D[2 * int64_t(t.sptr + lane)] = myd0;
-    D[2 * int64_t(t.sptr + lane) + 1] = 0.0;
+    D[2 * int64_t(t.sptr + lane) + 1] = myd1;
   }
   if (lane == 0) {
     fastok[t.iblk] = 1;
     atomicAdd(&stat[16 + STAT_BINS + (ti & (STAT_BINS - 1))], 1);
     if (nneg) atomicAdd(&stat[16 + (ti & (STAT_BINS - 1))], nneg);
+    if (ntwo) atomicAdd(&stat[3], ntwo);
   }
   if (!t.has_contrib || cm <= 0) return;
   double* Cb = C + t.coff;
@@ -4167,7 +4205,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
         const TinyFrontTask* tf = static_cast<const TinyFrontTask*>(F.tftasks) + lp.tf_begin;
         hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, tf, cnt, gl,
                            F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail,
-                           small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri);
+                           small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri, 0);
       } else {
       int beg = lp.tf_begin, cnt = 0, maxm = 0;
       static const int narrow_max = getenv("GSLS_NARROW_MAX") ? atoi(getenv("GSLS_NARROW_MAX")) : 2048;
@@ -4181,7 +4219,8 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
         const TinyFrontTask* tf = static_cast<const TinyFrontTask*>(F.tftasks) + beg;
         const int tri = (maxm * (maxm + 1) / 2 + 1) & ~1;
 #define GSLS_FW_ARGS tf, cnt, gl, F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, \
-                     F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri
+                     F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri, \
+                     (cls <= 2 ? (F.any_hint ? 1 : 0) : 0)
         switch (cls) {
           case 0:
             hipLaunchKernelGGL((k_front_wave<24, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
@@ -4195,6 +4234,10 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
           default:      // more than 32 columns: the blocked kernel (an unrolled 48-column body is 64 KB of code)
             hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, GSLS_FW_ARGS);
         }
+        if (cls <= 2 && F.any_hint)      // the fronts with learned 2x2 pivots that the unrolled kernel left alone
+          hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, tf, cnt, gl,
+                             F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail,
+                             small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri, 1);
 #undef GSLS_FW_ARGS
         beg += cnt;
         cnt = maxm = 0;

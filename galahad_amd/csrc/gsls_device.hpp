@@ -94,6 +94,7 @@ struct DeviceFactor {
   int64_t* adst_wg = nullptr;
   int64_t nscatter_wg = 0;
   const double* cur_val = nullptr; // the values of the factorization in flight
+  bool any_hint = false;           // the handle holds learned 2x2 pivots (F.hint has non-zero entries)
   double* xp_mr = nullptr;         // multi-column solves: up to 8 permuted vectors, xs_mr elements apart,
   double* cvec_mr = nullptr;       // and 8 copies of the contribution vectors, cs_mr apart
   int64_t xs_mr = 0, cs_mr = 0;

@@ -759,3 +759,45 @@ def test_empty_system():
     assert lib.gsls_factor(h, 0, None, None, C.byref(o), C.byref(inf)) == 0
     assert lib.gsls_solve(h, 0, 1, None, 0, C.byref(o), C.byref(inf)) == 0
     lib.gsls_destroy(C.byref(h))
+
+
+def test_learned_2x2_pivots_stay_on_the_wave_per_front_path():
+    """K = [0 B; B^T 0] with a sparse B: every pivot is 2x2.  After the first factorization has learned the pairs, the
+    refactorizations must run on the wave-per-front path (k_front_blk eliminates the hinted pairs inside its 4-column
+    panels) -- no front on the blacklist, the same inertia and solution every time."""
+    import ctypes as C
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    from galahad_amd._lib import lib
+    nb = 3000
+    rng = np.random.default_rng(5)
+    rows, cols, vals = [], [], []
+    for i in range(nb):
+        for j in (i - 1, i, i + 1):
+            if 0 <= j < nb:
+                rows.append(nb + j + 1)
+                cols.append(i + 1)
+                vals.append(4.0 if i == j else rng.uniform(-1, 1))
+    n = 2 * nb
+    row, col, val = np.array(rows, np.int32), np.array(cols, np.int32), np.array(vals)
+    xs = rng.uniform(-1, 1, n)
+    rhs = P.sym_matvec(n, row - 1, col - 1, val, xs)
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    c.pivot_control, c.node_amalgamation, c.max_iterative_refinements = 1, 16, 0
+    s.analyse(m, c, i)
+    xprev = None
+    for rep in range(3):
+        s.factorize(m, c, i)
+        assert i.status == 0, i.gsls_inform
+        assert i.negative_eigenvalues == nb and i.two_by_two_pivots == nb and i.rank == n
+        x = s.solve(m, rhs, c, i)
+        assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-13
+        fb, pb, bl = C.c_int32(), C.c_int32(), C.c_int32()
+        lib.gsls_get_factor_stats(s.handle, C.byref(fb), C.byref(pb), C.byref(bl))
+        if rep >= 1:
+            assert pb.value == 0 and bl.value == 0, (rep, fb.value, pb.value, bl.value)
+            if xprev is not None and rep >= 2:
+                assert np.array_equal(x, xprev)
+        xprev = x
+    s.terminate()
