@@ -78,6 +78,7 @@ SIGNATURES = {
     "gsls_comm_destroy": (C.c_int, [C.c_void_p]),
     "gsls_get_order": (C.c_int, [C.c_void_p, p_i32]),
     "gsls_get_scaling": (C.c_int, [C.c_void_p, p_f64]),
+    "gsls_shard_fast": (C.c_int, [C.c_void_p, i32]),
     "gsls_scale_sym": (C.c_int, [i32, i32, p_i64, p_i32, p_f64, i32, p_f64]),
     "gsls_refine_order_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
     "gsls_refine_order": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),

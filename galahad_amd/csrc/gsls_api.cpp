@@ -32,6 +32,8 @@ struct Handle {
   int tiny_strikes = 0;       // factorizations in which that kernel met a pivot it could not take
   std::vector<int> tiny_black;   // tiny fronts that kernel gave up on: they stay on the workgroup path
   std::vector<double> scale_host; // the scaling the last factorization computed itself (options.scaling > 0), else empty
+  bool shard_fast = false;        // multi-GPU: the last factorization needed no pivoting: tiny fronts on the wave kernels
+  bool shard_fast_off = false;    // ... unless that path has failed on this handle before
   int last_fast = 0, last_pivoted = 0, last_passes = 0;   // of the last factorization (gsls_get_factor_stats)
   bool own_order = false;     // analyse chose the elimination order itself (it may be refined when values arrive)
   bool preordered = false;    // ... and that refinement (zero-diagonal variables after their neighbours) has been done
@@ -301,6 +303,7 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
   h->analysed = h->factored = h->dev_ready = false;
   h->have_coo = h->coo_uploaded = false;
   h->learned = 0;
+  h->shard_fast = h->shard_fast_off = false;
   h->tiny_ready = false;
   h->tiny_strikes = 0;
   h->tiny_black.clear();
@@ -1237,7 +1240,7 @@ int gsls_shard_factor_dev(void* handle, int32_t phase, int32_t posdef, const dou
     h->tpp_dirty = false;
   }
   h->have_scale = false;
-  e = dev_shard_factor(S, h->F, phase, posdef != 0, d_val, d_xchg, options->small, options->u, h->stream);
+  e = dev_shard_factor(S, h->F, phase, posdef != 0, d_val, d_xchg, options->small, options->u, h->stream, h->shard_fast);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   int32_t st[16];
   e = read_stat(h, st);
@@ -1317,6 +1320,7 @@ int gsls_shard_failed(void* handle, int32_t* nfailed, int32_t* failed) {
 // Every rank must pass the same list; the result is identical on every rank.
 int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed_in, int64_t* xchg_factor_elems,
                       int64_t* xchg_solve_elems) {
+  if (handle) static_cast<Handle*>(handle)->shard_fast = false;      // the order changes: not before a clean pass again
   Handle* h = static_cast<Handle*>(handle);
   if (!h || !h->analysed || h->S.nranks < 2 || nfailed < 0 || (nfailed > 0 && !failed_in))
     return GSLS_ERROR_CALL_SEQUENCE;
@@ -1451,10 +1455,10 @@ int gsls_comm_factor_dev(void* handle, int32_t posdef, const double* d_val, cons
     }
     h->have_scale = false;
     const int64_t ce = h->F.xchgC_elems;
-    e = dev_shard_factor(h->S, h->F, 1, posdef != 0, d_val, h->cx_factor, options->small, options->u, h->stream);
+    e = dev_shard_factor(h->S, h->F, 1, posdef != 0, d_val, h->cx_factor, options->small, options->u, h->stream, h->shard_fast);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     NCCLCHK(ncclReduce(h->cx_factor, h->cx_factor, size_t(ce + 8), ncclDouble, ncclSum, 0, h->comm, h->stream));
-    e = dev_shard_factor(h->S, h->F, 2, posdef != 0, d_val, h->cx_factor, options->small, options->u, h->stream);
+    e = dev_shard_factor(h->S, h->F, 2, posdef != 0, d_val, h->cx_factor, options->small, options->u, h->stream, h->shard_fast);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     NCCLCHK(ncclBroadcast(h->cx_factor + ce, h->cx_factor + ce, 16, ncclDouble, 0, h->comm, h->stream));
     double st[16];
@@ -1466,9 +1470,15 @@ int gsls_comm_factor_dev(void* handle, int32_t posdef, const double* d_val, cons
     inform->maxfront = std::max(h->S.maxfront, h->S.maxrow);
     inform->num_neg = inform->num_two = 0;
     inform->num_delay = total_moved;
+    if (!posdef && st[5] + st[13] > 0) {      // a front on the wave-per-front path wanted pivoting: again without it
+      h->shard_fast = false;
+      h->shard_fast_off = true;
+      continue;
+    }
     if (posdef) {
       if (st[0] + st[8] > 0) { inform->time_factor = now() - t0; return inform->flag = GSLS_ERROR_NOT_POS_DEF; }
     } else if (st[1] + st[9] > 0) {
+      h->shard_fast = false;
       // failed pivots somewhere: every rank contributes its list, all apply the same repair and go again
       int32_t stat[16];
       e = hipMemcpy(stat, h->F.stat, sizeof(stat), hipMemcpyDeviceToHost);
@@ -1502,6 +1512,8 @@ int gsls_comm_factor_dev(void* handle, int32_t posdef, const double* d_val, cons
       continue;
     }
     if (!posdef) {
+      // no block needed pivoting anywhere: the next factorization may take the wave-per-front kernels
+      h->shard_fast = !h->shard_fast_off && (st[6] + st[14] == 0);
       inform->num_neg = int(st[2] + st[10]);
       inform->num_two = int(st[3] + st[11]);
       const int nzero = int(st[4] + st[12]);
@@ -1731,6 +1743,16 @@ int gsls_scale_sym(int32_t kind, int32_t n, const int64_t* ptr, const int32_t* r
   } catch (const std::bad_alloc&) {
     return GSLS_ERROR_ALLOCATION;
   }
+}
+
+// multi-GPU drivers that run the phases themselves (gsls_shard_*): after a factorization whose status words report no
+// pivoted block on any rank, `on` = 1 lets the next one take the wave-per-front kernels; 0 switches them off again
+// (to be called with the same value on every rank).  gsls_comm_factor_dev does this itself.
+int gsls_shard_fast(void* handle, int32_t on) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
+  h->shard_fast = on != 0;
+  return GSLS_SUCCESS;
 }
 
 // the scaling factors the last factorization computed itself (gsls_options.scaling = 1, 2, 4): what ssids_factor returns

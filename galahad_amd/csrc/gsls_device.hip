@@ -3419,13 +3419,15 @@ __global__ void k_permute_out_owned(int n, const int32_t* __restrict__ invp, con
 }
 // the factorization counters of this rank as doubles behind the contribution blocks of the exchange buffer, so that
 // ONE reduction carries data and status: [0] ranks that met a non-positive pivot (posdef), [1] failed columns
-// (delays), [2] negative pivots, [3] 2x2 pivots, [4] zero pivots
+// (delays), [2] negative pivots, [3] 2x2 pivots, [4] zero pivots, [5] fronts the wave-per-front kernels gave up on
+// (fast path: the factorization has to be repeated without it), [6] blocks / fronts that needed pivoting
 __global__ void k_stat_to_xchg(const int32_t* __restrict__ stat, double* __restrict__ out,
                                const double* __restrict__ minus) {     // minus: an earlier snapshot to subtract, or null
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int neg = stat[2];
   for (int b = 0; b < STAT_BINS; ++b) neg += stat[16 + b];
-  double v[8] = {(stat[0] != INT_MAX) ? 1.0 : 0.0, double(stat[4]), double(neg), double(stat[3]), double(stat[1]), 0.0, 0.0, 0.0};
+  double v[8] = {(stat[0] != INT_MAX) ? 1.0 : 0.0, double(stat[4]), double(neg), double(stat[3]), double(stat[1]),
+                 double(stat[13]), double(stat[7] + stat[14]), 0.0};   // [5] fronts the wave kernels gave up on, [6] pivoted
   for (int k = 0; k < 8; ++k) out[k] = v[k] - (minus ? minus[k] : 0.0);
   if (minus && out[0] < 0.0) out[0] = 0.0;
 }
@@ -3756,6 +3758,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   if (F.sharded) {
     build_plan(F.planA, [&](int s) { return S.owner[s] == F.myrank; }, all);
     build_plan(F.planB, [&](int s) { return S.owner[s] < 0; }, all);
+    // the same two with the tiny fronts on the wave-per-front kernels (refactorizations that need no pivoting)
+    build_plan(F.planAT, [&](int s) { return S.owner[s] == F.myrank; }, is_wg);
+    build_plan(F.planBT, [&](int s) { return S.owner[s] < 0; }, is_wg);
   }
 
   // ---- wave tier of the LDL^T solves: stages of small subtrees, one wave each ------------------------------
@@ -4843,8 +4848,10 @@ static void launch_segments(const DeviceFactor& F, const void* seg, double* aren
 }
 
 hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, const double* d_val,
-                            double* d_xchg, double small, double u, hipStream_t st) {
+                            double* d_xchg, double small, double u, hipStream_t st, bool fast) {
   if (!F.sharded) return hipErrorInvalidValue;
+  fast = fast && !posdef;
+  F.cur_val = d_val;
   if (phase == 1) {
     HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
     HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
@@ -4858,7 +4865,7 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
     }
     if (posdef) HIPCHK(ensure_linv(F));
     hipError_t e = posdef ? factor_levels<true>(S, F, F.planA, small, u, st, 1)
-                          : factor_levels<false>(S, F, F.planA, small, u, st, 1);
+                          : factor_levels<false>(S, F, fast ? F.planAT : F.planA, small, u, st, 1);
     if (e != hipSuccess) return e;
     launch_segments(F, F.segC, F.C, d_xchg, 0, st);
     hipLaunchKernelGGL(k_stat_to_xchg, dim3(1), dim3(64), 0, st, F.stat, d_xchg + F.xchgC_elems, static_cast<const double*>(nullptr));
@@ -4867,7 +4874,7 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
     if (F.myrank != 0) return hipSuccess;
     launch_segments(F, F.segC, F.C, d_xchg, 1, st);
     hipError_t e = posdef ? factor_levels<true>(S, F, F.planB, small, u, st, 2, false)
-                          : factor_levels<false>(S, F, F.planB, small, u, st, 2, false);
+                          : factor_levels<false>(S, F, fast ? F.planBT : F.planB, small, u, st, 2, false);
     if (e != hipSuccess) return e;
     // the top part's own counters = rank 0's counters now minus what they were after its subtrees
     hipLaunchKernelGGL(k_stat_to_xchg, dim3(1), dim3(64), 0, st, F.stat, d_xchg + F.xchgC_elems + 8,

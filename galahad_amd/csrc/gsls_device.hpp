@@ -122,6 +122,7 @@ struct DeviceFactor {
   std::vector<LevelPlan> planW;   // wave tier active: the fronts it does not cover (more than 64 rows)
   std::vector<LevelPlan> planA;   // multi-GPU: the subtrees this rank owns
   std::vector<LevelPlan> planB;   // multi-GPU: the top part (run by rank 0 after the exchange)
+  std::vector<LevelPlan> planAT, planBT;   // ... the same with the tiny fronts on the wave-per-front kernels
   bool sharded = false;
   int myrank = 0;
   // exchange buffers: contribution blocks / contribution vectors of the cut roots, packed in
@@ -205,7 +206,7 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);
 // multi-GPU phases (see gsls_shard_factor / gsls_shard_solve in include/gsls.h)
 hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, const double* d_val,
-                            double* d_xchg, double small, double u, hipStream_t st);
+                            double* d_xchg, double small, double u, hipStream_t st, bool fast = false);
 hipError_t dev_shard_solve(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, double* d_x,
                            double* d_xchg, hipStream_t st);
 

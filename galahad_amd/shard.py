@@ -155,14 +155,22 @@ class TreeShardedSLS:
             if worst < 0:
                 return {"flag": int(worst), "num_neg": 0, "num_two": 0, "matrix_rank": 0, "num_delay": moved}
             tot = st[:8] + st[8:]
+            if not posdef and tot[5] > 0:
+                # a front on the wave-per-front path wanted pivoting: the same factorization again without that path
+                lib.gsls_shard_fast(s.handle, 0)
+                self._fast_off = True
+                continue
             if posdef and tot[0] > 0:
                 return {"flag": -6, "num_neg": 0, "num_two": 0, "matrix_rank": 0, "num_delay": moved}
             if not posdef and tot[1] > 0:
+                lib.gsls_shard_fast(s.handle, 0)
                 flag, k = self._repair()
                 if flag != 0:
                     return {"flag": flag, "num_neg": 0, "num_two": 0, "matrix_rank": 0, "num_delay": moved}
                 moved += k
                 continue
+            if not posdef:      # no block needed pivoting on any rank: the next factorization takes the wave kernels
+                lib.gsls_shard_fast(s.handle, 1 if (tot[6] == 0 and not getattr(self, "_fast_off", False)) else 0)
             nzero = int(tot[4])
             flag = 0
             if nzero > 0:

@@ -273,6 +273,12 @@ int gsls_get_symbolic(void* handle, int32_t* sptr, int32_t* sparent, int64_t* rp
 int gsls_scale_sym(int32_t kind, int32_t n, const int64_t* ptr, const int32_t* row, const double* val, int32_t action,
                    double* scaling);
 
+/* multi-GPU, phase drivers only: status words [5] / [6] of the factor exchange are the fronts the wave-per-front
+ * kernels gave up on and the blocks that needed pivoting, summed over the ranks.  After a factorization with [6] = 0
+ * call gsls_shard_fast(h, 1) on every rank: the next one takes the wave-per-front kernels; if that one reports
+ * [5] > 0, call gsls_shard_fast(h, 0) and repeat it.  (gsls_comm_factor_dev does this itself.) */
+int gsls_shard_fast(void* handle, int32_t on);
+
 /* the scaling factors the last factorization computed itself (options.scaling = 1, 2, 4), in the caller's
  * variable order: the optional `scale` output of ssids_factor (src/ssids/ssids.f90:955-958, 983-986, 1021-1025) */
 int gsls_get_scaling(void* handle, double* scaling);

@@ -80,11 +80,23 @@ def main():
            "err_vs_exact": float(np.abs(x2 - xs).max()),
            "owners": sorted(set(int(o) for o in owner)), "ncut": int(len(cut)),
            "xsum": float(x2.sum())}
-    # a second factorize+solve on the same handle (refactorization path)
+    # a second and a third factorize+solve on the same handles: the refactorization path (when the first pass needed no
+    # pivoting both the single-device handle and the sharded one switch the tiny fronts to the wave-per-front kernels:
+    # the sharded result must be bitwise the single-device refactorization's), and its repeat
+    s1.factorize(m, c1, i1)
+    x1b = s1.solve(m, rhs.copy(), c1, i1)
     st = ts.factorize_dev(d_val, posdef)
     d_x = torch.from_numpy(rhs.copy()).cuda()
     ts.solve_dev(d_x)
-    res["repeat_bitwise"] = bool(np.array_equal(d_x.cpu().numpy(), x2))
+    x2b = d_x.cpu().numpy()
+    st = ts.factorize_dev(d_val, posdef)
+    d_x = torch.from_numpy(rhs.copy()).cuda()
+    ts.solve_dev(d_x)
+    x2c = d_x.cpu().numpy()
+    res["refactor_bitwise_vs_single"] = bool(np.array_equal(x2b, x1b))
+    res["refactor_max_abs_diff_vs_single"] = float(np.abs(x2b - x1b).max())
+    res["refactor_residual"] = float(P.scaled_residual(n, row, col, val, x2b, rhs))
+    res["repeat_bitwise"] = bool(np.array_equal(x2c, x2b))
     with open(out + ".%d" % rank, "w") as f:
         json.dump(res, f)
     s1.terminate()

@@ -51,8 +51,9 @@ def test_tree_sharded_matches_single_device(case, world, tmp_path):
         assert r["ncut"] >= world, r
         assert set(range(world)) <= set(r["owners"]), r      # every rank owns some subtree
         assert r["bitwise_equal"], r
+        assert r["refactor_bitwise_vs_single"], r         # refactorization: both sides on the wave-per-front kernels
         assert r["repeat_bitwise"], r
-        assert r["scaled_residual"] <= 1e-13, r
+        assert r["scaled_residual"] <= 1e-13 and r["refactor_residual"] <= 1e-13, r
         assert r["num_neg"] == r["ref_num_neg"] and r["num_two"] == r["ref_two"], r
         assert r["ref_delays"] == 0 and r["num_delay"] == 0, r
     assert len({r["xsum"] for r in res}) == 1          # every rank ends with the same solution
