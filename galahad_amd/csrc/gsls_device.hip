@@ -2995,9 +2995,12 @@ __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const
       }
     }
   }
-  if (t.flags & WT_INT) xfull[t.myslot * 64 + lane] = x;       // for the children inside the group
+  // pivot slot `lane` holds the analyse-time row gperm[sptr + lane] - sptr (numerical pivoting inside the front); the
+  // children address the front by analyse-time rows (cmap, gather lists)
+  const int arow = (lane < n) ? p.pos - t.sptr : lane;
+  if (t.flags & WT_INT) xfull[t.myslot * 64 + arow] = x;       // for the children inside the group
   if (PULLS && (t.flags & WT_PULL)) {                          // ... and for those of earlier stages
-    const int lr = min(lane, m - 1);
+    const int lr = min(arow, m - 1);
     const int g0 = gth_ptr[t.goff + lr], g1 = (lane < m) ? gth_ptr[t.goff + lr + 1] : g0;
     const int last = max(g1 - 1, g0);
     for (int g = g0; __any(g < g1); g += 8) {                  // eight destinations' indices in flight at a time

@@ -801,3 +801,41 @@ def test_learned_2x2_pivots_stay_on_the_wave_per_front_path():
                 assert np.array_equal(x, xprev)
         xprev = x
     s.terminate()
+
+
+def test_wave_tier_backward_with_pivoting_inside_a_front():
+    """regression (found by tools/soak.py, seed 4, system 55): a 227-variable indefinite system whose accepted
+    factorization still holds a front with numerical pivoting inside (gperm not the identity there).  The wave tier's
+    backward step handed the front's solution to its children by pivot slot instead of by analyse-time row: status 0,
+    correct inertia, solution wrong by 0.4.  Forward, D and backward part solves and the full solve against numpy."""
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    g = np.load(os.path.join(HERE, "data", "soak_seed4_it55.npz"))
+    A, rhs = g["A"], g["rhs"]
+    n = A.shape[0]
+    r, c = np.nonzero(np.tril(A))
+    m = SMT(n, "COORDINATE", row=(r + 1).astype(np.int32), col=(c + 1).astype(np.int32), val=A[r, c])
+    s, ctl, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", ctl, i)
+    ctl.pivot_control, ctl.node_amalgamation, ctl.max_iterative_refinements = 1, int(g["nemin"]), 0
+    s.analyse(m, ctl, i)
+    xd = np.linalg.solve(A, rhs)
+    for rep in range(3):
+        s.factorize(m, ctl, i)
+        assert i.status == 0 and i.negative_eigenvalues == int((np.linalg.eigvalsh(A) < 0).sum())
+        x = s.solve(m, rhs, ctl, i)
+        assert np.abs(x - xd).max() <= 1e-10, rep
+        y = s.part_solve("L", rhs.copy(), ctl, i)
+        z = s.part_solve("D", y, ctl, i)
+        x2 = s.part_solve("U", z, ctl, i)
+        assert np.abs(x2 - xd).max() <= 1e-10, rep
+    s.terminate()
+
+
+def test_randomised_soak():
+    """tools/soak.py on 240 seeded systems (SPD / indefinite / saddle / weak diagonals, 5..260 variables, own ordering or
+    random PERM, nemin 1..64, three factorizations each) against numpy: solutions, inertia, rank."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "soak.py"), "240", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "0 failures" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -1,0 +1,80 @@
+"""Randomised soak: many small sparse symmetric systems of varied structure (SPD / indefinite / saddle, own ordering or
+natural, several supernode widths) through analyse -> factorize x3 -> solve, every solution against numpy's dense solve
+and the inertia against the eigenvalues.  Prints the failures (seed and shape) and a summary."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from galahad_amd import SLS, SMT, Control, InformSLS
+
+def make(rng, kind, n):
+    dens = rng.uniform(1.5, 6.0) / n
+    M = np.where(rng.uniform(size=(n, n)) < dens, rng.uniform(-1, 1, (n, n)), 0.0)
+    A = np.tril(M, -1); A = A + A.T
+    if kind == "spd":
+        A += np.diag(np.abs(A).sum(1) + rng.uniform(0.1, 1.0, n))
+    elif kind == "indef":
+        A += np.diag(rng.choice([-1.0, 1.0], n) * (np.abs(A).sum(1) * rng.uniform(0.3, 1.5) + 0.1))
+    elif kind == "weakdiag":
+        A += np.diag(rng.uniform(-0.3, 0.3, n))
+        A += np.diag(np.where(np.abs(A).sum(1) == 0, 1.0, 0.0))
+    else:  # saddle: [H B^T; B 0]
+        k = n // 3
+        H = A[: n - k, : n - k] + np.diag(np.abs(A[: n - k, : n - k]).sum(1) + 0.5)
+        B = np.where(rng.uniform(size=(k, n - k)) < 3.0 / (n - k), rng.uniform(-1, 1, (k, n - k)), 0.0)
+        for i in range(k):
+            B[i, rng.integers(0, n - k)] += 1.0 + rng.uniform()
+            B[i, (7 * i) % (n - k)] += 1.0
+        A = np.zeros((n, n)); A[: n - k, : n - k] = H; A[n - k:, : n - k] = B; A[: n - k, n - k:] = B.T
+    return A
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0; skipped = 0
+    only = int(os.environ.get("SOAK_ONLY", "-1"))
+    for it in range(N):
+        kind = ["spd", "indef", "saddle", "weakdiag"][it % 4]
+        n = int(rng.integers(5, 260))
+        A = make(rng, kind, n)
+        ev = np.linalg.eigvalsh(A)
+        if np.abs(ev).min() < 1e-8 * np.abs(ev).max():
+            skipped += 1; continue
+        r, c = np.nonzero(np.tril(A)); 
+        if not (A[np.arange(n), np.arange(n)] != 0).all():   # keep explicit zero diagonals out of COO: pattern without them
+            pass
+        row, col, val = (r + 1).astype(np.int32), (c + 1).astype(np.int32), A[r, c]
+        xs = rng.uniform(-1, 1, n); rhs = A @ xs
+        nem = int(rng.choice([1, 4, 8, 16, 24, 32, 64]))
+        own = it % 3 != 0
+        permr = None if own else rng.permutation(n) + 1        # (same draws in the same order whether or not the case runs)
+        if only >= 0 and it != only:
+            continue
+        if only >= 0:
+            np.savez("/tmp/soak_case.npz", A=A, rhs=rhs, xs=xs, nemin=nem, perm=np.zeros(0) if own else permr, kind=kind)
+        m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+        s, ctl, i = SLS(), Control(), InformSLS(); s.initialize("gsls", ctl, i)
+        ctl.pivot_control = 2 if kind == "spd" and it % 8 < 4 else 1
+        ctl.node_amalgamation = nem
+        ctl.max_iterative_refinements = 0
+        s.analyse(m, ctl, i) if own else s.analyse(m, ctl, i, PERM=permr)
+        xd = np.linalg.solve(A, rhs)
+        cond = np.abs(ev).max() / np.abs(ev).min()
+        for rep in range(3):
+            s.factorize(m, ctl, i)
+            ok = i.status == 0
+            if ok:
+                x = s.solve(m, rhs, ctl, i)
+                err = np.abs(x - xd).max() / max(1.0, np.abs(xd).max())
+                ok = err <= 1e-11 * max(cond, 1e2) and i.negative_eigenvalues == int((ev < 0).sum()) and i.rank == n
+            if not ok:
+                bad += 1
+                print("FAIL it %d kind %s n %d nemin %d own %d rep %d status %d neg %d/%d err %.2e cond %.1e" % (
+                    it, kind, n, ctl.node_amalgamation, own, rep, i.status, i.negative_eigenvalues, int((ev < 0).sum()),
+                    err if i.status == 0 else -1, cond), flush=True)
+                break
+        s.terminate()
+    print("soak: %d systems, %d skipped (singular), %d failures" % (N, skipped, bad))
+    return 1 if bad else 0
+
+sys.exit(main())
