@@ -1449,7 +1449,8 @@ template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         double* __restrict__ L, const double* __restrict__ D, const int32_t* __restrict__ gperm,
-        int32_t* __restrict__ stat, int32_t* __restrict__ faillist, double u, const uint8_t* __restrict__ tppflag) {
+        int32_t* __restrict__ stat, int32_t* __restrict__ faillist, double u, const uint8_t* __restrict__ tppflag,
+        double small) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Stage<RB>& sg = *reinterpret_cast<Stage<RB>*>(smem_raw);
   double* Pc = reinterpret_cast<double*>(smem_raw);                  // [w][RBP]
@@ -1585,6 +1586,10 @@ k_panel(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ tasks,
         const double l = aj * dsc[2 * j];
         *out = l;
         if (fabs(l) > inv_u) bigcol = min(bigcol, j);
+        // a column the diagonal kernel declared a ZERO pivot (it sees the first 128 rows of the front only) that
+        // has a non-negligible entry down here is not a zero column (ldlt_tpp.cxx:250-262 tests the whole column):
+        // it failed, like any column whose multipliers are too large
+        if (dsc[2 * j] == 0.0 && !(fabs(aj) < small)) bigcol = min(bigcol, j);
       }
     }
   }
@@ -4283,7 +4288,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
                              F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.Linv);
         else
           hipLaunchKernelGGL(k_panel<false>, dim3(lp.panel_cnt[2 * s + 1]), dim3(256), lds_panel, st, F.nodes,
-                             F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u, F.tppflag);
+                             F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u, F.tppflag, small);
       }
     }
     if (!POSDEF && &plan == &F.planT && l < int(F.bl_level.size()) && F.bl_level[l].np > 0) {

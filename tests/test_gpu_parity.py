@@ -839,3 +839,29 @@ def test_randomised_soak():
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "soak.py"), "240", "11"],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "0 failures" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_zero_pivot_needs_the_whole_column_to_be_negligible():
+    """regression (tools/soak.py, SOAK_BIG=1, seed 22, system 42): a 2158-variable saddle system under a random PERM.  A
+    column whose entries were all zero inside the first 128 rows of a tall front -- all the diagonal kernel sees -- was
+    declared a zero pivot although it had entries further down (the panel kernel then multiplied them by 0): status 0,
+    two negative eigenvalues missing, solution wrong by 0.46.  The reference tests the whole column
+    (ldlt_tpp.cxx:250-262); k_panel now reports such a column as failed and it is delayed like any other."""
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    g = np.load(os.path.join(HERE, "data", "soak_big_seed22_it42.npz"))
+    n, row, col, val, rhs, xs = int(g["n"]), g["row"], g["col"], g["val"], g["rhs"], g["xs"]
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s, ctl, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", ctl, i)
+    ctl.pivot_control, ctl.node_amalgamation, ctl.max_iterative_refinements = 1, int(g["nemin"]), 0
+    s.analyse(m, ctl, i, PERM=g["perm"])
+    import scipy.sparse as sp
+    A = sp.coo_matrix((val, (row - 1, col - 1)), shape=(n, n)).toarray()
+    A = A + A.T - np.diag(np.diag(A))
+    nneg = int((np.linalg.eigvalsh(A) < 0).sum())
+    for rep in range(2):
+        s.factorize(m, ctl, i)
+        assert i.status == 0 and i.rank == n and i.negative_eigenvalues == nneg, (rep, i.rank, i.negative_eigenvalues, nneg)
+        x = s.solve(m, rhs, ctl, i)
+        assert np.abs(x - xs).max() <= 1e-9
+    s.terminate()

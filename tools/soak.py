@@ -8,7 +8,7 @@ import numpy as np
 from galahad_amd import SLS, SMT, Control, InformSLS
 
 def make(rng, kind, n):
-    dens = rng.uniform(1.5, 6.0) / n
+    dens = (rng.uniform(1.5, 12.0) if os.environ.get("SOAK_BIG") else rng.uniform(1.5, 6.0)) / n
     M = np.where(rng.uniform(size=(n, n)) < dens, rng.uniform(-1, 1, (n, n)), 0.0)
     A = np.tril(M, -1); A = A + A.T
     if kind == "spd":
@@ -35,7 +35,7 @@ def main():
     only = int(os.environ.get("SOAK_ONLY", "-1"))
     for it in range(N):
         kind = ["spd", "indef", "saddle", "weakdiag"][it % 4]
-        n = int(rng.integers(5, 260))
+        n = int(rng.integers(300, 2500)) if os.environ.get("SOAK_BIG") else int(rng.integers(5, 260))
         A = make(rng, kind, n)
         ev = np.linalg.eigvalsh(A)
         if np.abs(ev).min() < 1e-8 * np.abs(ev).max():
@@ -57,6 +57,8 @@ def main():
         ctl.pivot_control = 2 if kind == "spd" and it % 8 < 4 else 1
         ctl.node_amalgamation = nem
         ctl.max_iterative_refinements = 0
+        if kind != "spd" and it % 5 == 4:
+            ctl.scaling = -1 if it % 10 == 4 else -2          # the backend's own scalings
         s.analyse(m, ctl, i) if own else s.analyse(m, ctl, i, PERM=permr)
         xd = np.linalg.solve(A, rhs)
         cond = np.abs(ev).max() / np.abs(ev).min()
@@ -64,9 +66,14 @@ def main():
             s.factorize(m, ctl, i)
             ok = i.status == 0
             if ok:
-                x = s.solve(m, rhs, ctl, i)
+                if it % 7 == 3:           # several right-hand sides at once
+                    X = s.solve(m, np.column_stack([rhs, 2 * rhs, -rhs]), ctl, i)
+                    lin = max(np.abs(X[:, 1] - 2 * X[:, 0]).max(), np.abs(X[:, 2] + X[:, 0]).max())
+                    x = X[:, 0] if lin <= 1e-9 * max(1.0, np.abs(X).max()) else X[:, 0] * np.nan
+                else:
+                    x = s.solve(m, rhs, ctl, i)
                 err = np.abs(x - xd).max() / max(1.0, np.abs(xd).max())
-                ok = err <= 1e-11 * max(cond, 1e2) and i.negative_eigenvalues == int((ev < 0).sum()) and i.rank == n
+                ok = (err <= 1e-11 * max(cond, 1e2)) and i.negative_eigenvalues == int((ev < 0).sum()) and i.rank == n
             if not ok:
                 bad += 1
                 print("FAIL it %d kind %s n %d nemin %d own %d rep %d status %d neg %d/%d err %.2e cond %.1e" % (
