@@ -831,13 +831,19 @@ def test_wave_tier_backward_with_pivoting_inside_a_front():
     s.terminate()
 
 
-def test_randomised_soak():
-    """tools/soak.py on 240 seeded systems (SPD / indefinite / saddle / weak diagonals, 5..260 variables, own ordering or
-    random PERM, nemin 1..64, three factorizations each) against numpy: solutions, inertia, rank."""
+@pytest.mark.parametrize("mode,count,seed", [("", 240, 11), ("SOAK_WIDE", 60, 12), ("SOAK_BIG", 24, 13)])
+def test_randomised_soak(mode, count, seed):
+    """tools/soak.py on seeded systems against numpy (solutions, inertia, rank; three factorizations each, some with the
+    backend's scalings, several right-hand sides, refinement on the device): 240 small ones (SPD / indefinite / saddle /
+    weak diagonals, 5..260 variables, own ordering or random PERM, nemin 1..64), 60 with wide fronts (dense, banded,
+    arrow; diagonally dominant or far from it), 24 bigger sparse ones (300..2500 variables)."""
     import subprocess
     import sys
-    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "soak.py"), "240", "11"],
-                       capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if mode:
+        env[mode] = "1"
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "soak.py"), str(count), str(seed)],
+                       capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and "0 failures" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 

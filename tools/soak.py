@@ -7,6 +7,28 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from galahad_amd import SLS, SMT, Control, InformSLS
 
+def make_structured(rng, kind, n):
+    """shapes that give wide fronts: dense, banded, arrow (a dense border), each definite or not"""
+    if kind == "dense":
+        B = rng.uniform(-1, 1, (n, n)); A = (B + B.T) / 2
+    elif kind == "band":
+        bw = min(int(rng.integers(20, 220)), n - 1); A = np.zeros((n, n))
+        for d in range(1, bw + 1):
+            v = rng.uniform(-1, 1, n - d) * (rng.uniform(size=n - d) < 0.7)
+            A[np.arange(d, n), np.arange(0, n - d)] = v
+        A = A + A.T
+    else:  # arrow
+        k = min(int(rng.integers(30, 300)), n - 1); A = np.zeros((n, n))
+        A[n - k:, :] = rng.uniform(-1, 1, (k, n)) * (rng.uniform(size=(k, n)) < 0.5)
+        A = np.tril(A, -1); A = A + A.T
+        i = np.arange(n - 1); A[i + 1, i] += rng.uniform(-1, 1, n - 1); A[i, i + 1] = A[i + 1, i]
+    sgn = np.ones(n) if rng.uniform() < 0.4 else rng.choice([-1.0, 1.0], n)
+    weak = rng.uniform() < 0.4                      # far from diagonal dominance: real pivoting on wide fronts
+    fac = rng.uniform(0.02, 0.3) if weak else rng.uniform(0.6, 1.3)
+    A[np.arange(n), np.arange(n)] = sgn * (np.abs(A).sum(1) * fac + 0.1)
+    return A, bool((sgn > 0).all()) and not weak
+
+
 def make(rng, kind, n):
     dens = (rng.uniform(1.5, 12.0) if os.environ.get("SOAK_BIG") else rng.uniform(1.5, 6.0)) / n
     M = np.where(rng.uniform(size=(n, n)) < dens, rng.uniform(-1, 1, (n, n)), 0.0)
@@ -36,7 +58,13 @@ def main():
     for it in range(N):
         kind = ["spd", "indef", "saddle", "weakdiag"][it % 4]
         n = int(rng.integers(300, 2500)) if os.environ.get("SOAK_BIG") else int(rng.integers(5, 260))
-        A = make(rng, kind, n)
+        if os.environ.get("SOAK_WIDE"):          # wide fronts: dense / banded / arrow
+            kind = ["dense", "band", "arrow"][it % 3]
+            n = int(rng.integers(70, 900))
+            A, definite = make_structured(rng, kind, n)
+            kind = "spd" if definite else kind
+        else:
+            A = make(rng, kind, n)
         ev = np.linalg.eigvalsh(A)
         if np.abs(ev).min() < 1e-8 * np.abs(ev).max():
             skipped += 1; continue
@@ -57,6 +85,8 @@ def main():
         ctl.pivot_control = 2 if kind == "spd" and it % 8 < 4 else 1
         ctl.node_amalgamation = nem
         ctl.max_iterative_refinements = 0
+        if it % 6 == 5:
+            ctl.max_iterative_refinements = 1                  # SLS_solve_ir on the device
         if kind != "spd" and it % 5 == 4:
             ctl.scaling = -1 if it % 10 == 4 else -2          # the backend's own scalings
         s.analyse(m, ctl, i) if own else s.analyse(m, ctl, i, PERM=permr)
