@@ -114,4 +114,5 @@ def main():
     print("soak: %d systems, %d skipped (singular), %d failures" % (N, skipped, bad))
     return 1 if bad else 0
 
-sys.exit(main())
+if __name__ == "__main__":
+    sys.exit(main())
