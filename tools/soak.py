@@ -110,6 +110,33 @@ def main():
                     it, kind, n, ctl.node_amalgamation, own, rep, i.status, i.negative_eigenvalues, int((ev < 0).sum()),
                     err if i.status == 0 else -1, cond), flush=True)
                 break
+        # the same pattern with other values (what an interior-point or trust-region iteration does): the learned order,
+        # hints and fast paths must either still work or fall back -- never give a wrong answer
+        for drift in range(2 if i.status == 0 else 0):
+            f = 10.0 ** rng.uniform(-1.5, 1.5, n) if drift == 0 else 1.0 + 0.5 * rng.uniform(-1, 1, n)
+            val2 = val * np.where(row == col, f[row - 1], 1.0 + 0.3 * rng.uniform(-1, 1, len(val)))
+            A2 = np.zeros((n, n)); A2[row - 1, col - 1] = val2; A2 = A2 + A2.T - np.diag(np.diag(A2))
+            ev2 = np.linalg.eigvalsh(A2)
+            if np.abs(ev2).min() < 1e-8 * np.abs(ev2).max():
+                continue
+            m2 = SMT(n, "COORDINATE", row=row, col=col, val=val2)
+            rhs2 = A2 @ xs
+            if ctl.pivot_control == 2 and ev2.min() <= 0:
+                continue
+            s.factorize(m2, ctl, i)
+            ok = i.status == 0
+            err = -1.0
+            if ok:
+                x = s.solve(m2, rhs2, ctl, i)
+                xd2 = np.linalg.solve(A2, rhs2)
+                cond2 = np.abs(ev2).max() / np.abs(ev2).min()
+                err = np.abs(x - xd2).max() / max(1.0, np.abs(xd2).max())
+                ok = (err <= 1e-11 * max(cond2, 1e2)) and i.negative_eigenvalues == int((ev2 < 0).sum()) and i.rank == n
+            if not ok:
+                bad += 1
+                print("FAIL(drift %d) it %d kind %s n %d nemin %d own %d status %d neg %d/%d err %.2e" % (
+                    drift, it, kind, n, ctl.node_amalgamation, own, i.status, i.negative_eigenvalues, int((ev2 < 0).sum()), err), flush=True)
+                break
         s.terminate()
     print("soak: %d systems, %d skipped (singular), %d failures" % (N, skipped, bad))
     return 1 if bad else 0
