@@ -104,6 +104,28 @@ def main():
                     x = s.solve(m, rhs, ctl, i)
                 err = np.abs(x - xd).max() / max(1.0, np.abs(xd).max())
                 ok = (err <= 1e-11 * max(cond, 1e2)) and i.negative_eigenvalues == int((ev < 0).sum()) and i.rank == n
+                if ok and it % 4 == 1 and ctl.max_iterative_refinements == 0:
+                    # SLS_part_solve: L, D, U compose to the solve; the pivots SLS_enquire returns carry the inertia
+                    y = s.part_solve("L", rhs.copy(), ctl, i)
+                    z = s.part_solve("D", y, ctl, i)
+                    x3 = s.part_solve("U", z, ctl, i)
+                    perr = np.abs(x3 - x).max() / max(1.0, np.abs(x).max())
+                    if ctl.pivot_control == 2:
+                        d = s.enquire(i, want_d=True)["D"][0]
+                        ineg = int((d < 0).sum())
+                    else:
+                        out = s.enquire(i, want_pivots=True, want_d=True)
+                        piv, d = out["PIVOTS"], out["D"]
+                        order = np.argsort(np.abs(piv)); ineg = 0; k = 0
+                        while k < n:                      # D is stored inverted, in pivot order; 2x2: negative PIVOTS pairs
+                            if piv[order[k]] > 0:
+                                ineg += d[0, k] < 0; k += 1
+                            else:
+                                det = d[0, k] * d[0, k + 1] - d[1, k] ** 2
+                                ineg += 1 if det < 0 else (2 if d[0, k] + d[0, k + 1] < 0 else 0); k += 2
+                    ok = perr <= 1e-12 * max(cond, 1e2) and ineg == int((ev < 0).sum())
+                    if not ok:
+                        err = -perr
             if not ok:
                 bad += 1
                 print("FAIL it %d kind %s n %d nemin %d own %d rep %d status %d neg %d/%d err %.2e cond %.1e" % (
