@@ -185,3 +185,16 @@ def test_dropin_minimum_degree_ordering_through_real_sls():
     assert (amd["status_analyse"], amd["status_factorize"], amd["status_solve"]) == (0, 0, 0)
     assert amd["entries_in_factors"] <= 0.6 * nat["entries_in_factors"]
     assert np.abs(amd["x"] - xs).max() <= 1e-9
+
+
+@pytest.mark.gpu
+def test_randomised_soak_through_the_real_facade():
+    """tools/soak_facade.py: 60 seeded systems as untidy COO (duplicates, upper-triangle and out-of-range entries) through
+    the reference's own sls.f90 + the gsls arms, with PERM / AMD / own ordering, scalings -1 / -2 and refinement, against
+    numpy's dense solve (solution, inertia, rank)."""
+    import subprocess
+    import sys
+    _need_dropin()
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "soak_facade.py"), "60", "5"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "0 failures" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
