@@ -658,8 +658,8 @@ k_diag_fast(const NodeDesc* __restrict__ nodes, const PanelTask* __restrict__ ta
 // that front on the workgroup path (which has the pivoting fallbacks).  A front with a hinted 2x2 pivot fails at once.
 // =================================================================================================
 constexpr int TINY_N = 64;
-constexpr int TINY_CLASSES = 5;                     // unrolled for 24, 28, 32 and 48 columns; up to 64: k_front_blk
-static inline int tiny_class(int n) { return n <= 24 ? 0 : n <= 28 ? 1 : n <= 32 ? 2 : n <= 48 ? 3 : 4; }
+constexpr int TINY_CLASSES = 5;                     // unrolled for 24, 28, 32 and 36 columns; up to 64: k_front_blk
+static inline int tiny_class(int n) { return n <= 24 ? 0 : n <= 28 ? 1 : n <= 32 ? 2 : n <= 36 ? 3 : 4; }
 struct TinyFrontTask {
   int32_t n, m, ld, sptr;
   int64_t loff, coff;
@@ -3181,8 +3181,8 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
   // learned 2x2 pivots: bit c = columns (c, c+1) are eliminated together
   const bool h2 = (lane < n) ? (hint[t.sptr + lane] != 0) : false;
   const unsigned long long hm = __ballot(h2);
-  // mode 1: the pass behind the unrolled kernels -- only the fronts of at most 32 columns they left alone (hinted ones)
-  if (mode == 1 && (n > 32 || hm == 0ull)) return;
+  // mode 1: the pass behind the unrolled kernels -- only the fronts of at most 36 columns they left alone (hinted ones)
+  if (mode == 1 && (n > 36 || hm == 0ull)) return;
   double* Fr = fsh + wave * (tri + 512);        // the triangle, then the panel scratch: L[row][4], (L D)[row][4]
   double2_t* P = reinterpret_cast<double2_t*>(Fr + tri);
   double2_t* PD = P + 128;
@@ -3506,6 +3506,7 @@ static hipError_t allow_big_lds() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<24, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<28, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_wave<36, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_chol_mr<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(MR_LDS_CAP)));
@@ -4233,7 +4234,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
         const int tri = (maxm * (maxm + 1) / 2 + 1) & ~1;
 #define GSLS_FW_ARGS tf, cnt, gl, F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, \
                      F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri, \
-                     (cls <= 2 ? (F.any_hint ? 1 : 0) : 0)
+                     (cls <= 3 ? (F.any_hint ? 1 : 0) : 0)
         switch (cls) {
           case 0:
             hipLaunchKernelGGL((k_front_wave<24, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
@@ -4244,10 +4245,13 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
           case 2:
             hipLaunchKernelGGL((k_front_wave<32, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
             break;
-          default:      // more than 32 columns: the blocked kernel (an unrolled 48-column body is 64 KB of code)
+          case 3:
+            hipLaunchKernelGGL((k_front_wave<36, 4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * tri * 8, st, GSLS_FW_ARGS);
+            break;
+          default:      // more than 36 columns: the blocked kernel (an unrolled 48-column body is 64 KB of code)
             hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, GSLS_FW_ARGS);
         }
-        if (cls <= 2 && F.any_hint)      // the fronts with learned 2x2 pivots that the unrolled kernel left alone
+        if (cls <= 3 && F.any_hint)      // the fronts with learned 2x2 pivots that the unrolled kernel left alone
           hipLaunchKernelGGL((k_front_blk<4>), dim3((cnt + 3) / 4), dim3(256), size_t(4) * (tri + 512) * 8, st, tf, cnt, gl,
                              F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, F.tinyskip, F.tinyfail,
                              small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri, 1);
