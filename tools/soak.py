@@ -92,6 +92,17 @@ def main():
         s.analyse(m, ctl, i) if own else s.analyse(m, ctl, i, PERM=permr)
         xd = np.linalg.solve(A, rhs)
         cond = np.abs(ev).max() / np.abs(ev).min()
+        if kind == "indef" and it % 16 == 5 and ev.min() < 0:
+            # asked for a Cholesky factorization of an indefinite matrix: must be refused (SSIDS_ERROR_NOT_POS_DEF ->
+            # GALAHAD_error_inertia), never "succeed"
+            ctl.pivot_control = 2
+            s.analyse(m, ctl, i) if own else s.analyse(m, ctl, i, PERM=permr)
+            s.factorize(m, ctl, i)
+            if i.status == 0:
+                bad += 1
+                print("FAIL it %d: Cholesky of an indefinite matrix (n %d, %d negative eigenvalues) returned status 0" % (it, n, int((ev < 0).sum())), flush=True)
+            s.terminate()
+            continue
         for rep in range(3):
             s.factorize(m, ctl, i)
             ok = i.status == 0
