@@ -29,7 +29,27 @@ def make_structured(rng, kind, n):
     return A, bool((sgn > 0).all()) and not weak
 
 
+def make_ipm(rng, n):
+    """interior-point KKT system with slacks, K = [H+D 0 A^T; 0 Ds -I; A -I 0] (what CQP hands to SBLS): H tridiagonal,
+    barrier terms spanning many decades"""
+    m = max(1, n // 5); nx = n - 2 * m
+    if nx < 2:
+        nx, m = n - 2, 1
+    K = np.zeros((n, n))
+    i = np.arange(nx)
+    K[i, i] = 2.0 + 10.0 ** rng.uniform(-3, 3, nx)
+    K[i[1:], i[:-1]] = -1.0; K[i[:-1], i[1:]] = -1.0
+    for c in range(m):
+        cols = rng.choice(nx, size=min(nx, int(rng.integers(1, 4))), replace=False)
+        K[nx + m + c, cols] = rng.uniform(0.5, 1.5, len(cols)); K[cols, nx + m + c] = K[nx + m + c, cols]
+        K[nx + c, nx + c] = 10.0 ** rng.uniform(-4, 4)               # y / s
+        K[nx + m + c, nx + c] = -1.0; K[nx + c, nx + m + c] = -1.0
+    return K
+
+
 def make(rng, kind, n):
+    if kind == "ipm":
+        return make_ipm(rng, n)
     dens = (rng.uniform(1.5, 12.0) if os.environ.get("SOAK_BIG") else rng.uniform(1.5, 6.0)) / n
     M = np.where(rng.uniform(size=(n, n)) < dens, rng.uniform(-1, 1, (n, n)), 0.0)
     A = np.tril(M, -1); A = A + A.T
@@ -56,7 +76,7 @@ def main():
     bad = 0; skipped = 0
     only = int(os.environ.get("SOAK_ONLY", "-1"))
     for it in range(N):
-        kind = ["spd", "indef", "saddle", "weakdiag"][it % 4]
+        kind = ["spd", "indef", "saddle", "weakdiag", "ipm"][it % 5] if os.environ.get("SOAK_IPM") else ["spd", "indef", "saddle", "weakdiag"][it % 4]
         n = int(rng.integers(300, 2500)) if os.environ.get("SOAK_BIG") else int(rng.integers(5, 260))
         if os.environ.get("SOAK_WIDE"):          # wide fronts: dense / banded / arrow
             kind = ["dense", "band", "arrow"][it % 3]
@@ -114,7 +134,9 @@ def main():
                 else:
                     x = s.solve(m, rhs, ctl, i)
                 err = np.abs(x - xd).max() / max(1.0, np.abs(xd).max())
-                ok = (err <= 1e-11 * max(cond, 1e2)) and i.negative_eigenvalues == int((ev < 0).sum()) and i.rank == n
+                res = np.abs(A @ x - rhs).max() / (np.abs(A).max() * max(1.0, np.abs(x).max()) + np.abs(rhs).max())
+                ok = (err <= 1e-11 * max(cond, 1e2) or (cond > 1e8 and res <= 1e-11)) and \
+                    i.negative_eigenvalues == int((ev < 0).sum()) and i.rank == n
                 if ok and it % 4 == 1 and ctl.max_iterative_refinements == 0:
                     # SLS_part_solve: L, D, U compose to the solve; the pivots SLS_enquire returns carry the inertia
                     y = s.part_solve("L", rhs.copy(), ctl, i)
