@@ -1834,6 +1834,36 @@ k_contrib_tiny(const TinyContribTask* __restrict__ tasks, int ntask, const doubl
   }
 }
 
+// Several right-hand sides through ONE launch of a solve kernel: the grid is R times as long, block b works on column
+// b % R of task b / R (the R columns of a front next to each other in dispatch order: L comes from HBM once and from
+// the caches R - 1 times, and a sweep that is bound by latency gets R times the waves in flight).  The columns'
+// work vectors lie at fixed strides; R = 1: one column, strides unused.
+struct Cols {
+  int R;
+  int64_t sx, sxs, scv, syb, spt, sio;   // xp, slot vector, contribution vectors, ybuf, part, the caller's columns
+};
+#define GSLS_COLS                                                          \
+  const int col_ = cs.R > 1 ? int(blockIdx.x % unsigned(cs.R)) : 0;        \
+  const unsigned bid = cs.R > 1 ? blockIdx.x / unsigned(cs.R) : blockIdx.x
+
+// permutation kernels for R columns at once: grid (blocks, R)
+__global__ void k_permute_in_cols(int n, const int32_t* __restrict__ invp, const double* __restrict__ x, int64_t ldx,
+                                  const double* __restrict__ scale, double* __restrict__ xp, int64_t sx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = invp[i];
+  x += blockIdx.y * ldx;
+  xp[blockIdx.y * sx + i] = scale ? x[v] * scale[v] : x[v];
+}
+__global__ void k_permute_out_cols(int n, const int32_t* __restrict__ invp, const double* __restrict__ xp, int64_t sx,
+                                   const double* __restrict__ scale, double* __restrict__ x, int64_t ldx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = invp[i];
+  xp += blockIdx.y * sx;
+  x[blockIdx.y * ldx + v] = scale ? xp[i] * scale[v] : xp[i];
+}
+
 // =================================================================================================
 // Solve kernels (v0: one workgroup per front, level by level)
 // =================================================================================================
@@ -1933,9 +1963,12 @@ __global__ void __launch_bounds__(256)
 k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
             const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
             const int32_t* __restrict__ gperm, const double* __restrict__ L,
-            double* __restrict__ xp, double* __restrict__ cvec) {
+            double* __restrict__ xp, double* __restrict__ cvec, Cols cs) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const NodeDesc nd = nodes[lvl[blockIdx.x]];
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  cvec += col_ * cs.scv;
+  const NodeDesc nd = nodes[lvl[bid]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nd.n, cm = nd.m - nd.n;
   double* blk = sh;                 // 64 x SB
@@ -2001,8 +2034,10 @@ k_solve_fwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
 // x <- D^-1 x in pivot order; D holds inverted pivots, 2x2 blocks as [d11,d21,inf,d22]
 // (ldlt_app.cxx:2550-2571 ldlt_app_solve_diag)
 __global__ void k_solve_diag(int n, const double* __restrict__ D, const int32_t* __restrict__ gperm,
-                             double* __restrict__ xp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                             double* __restrict__ xp, Cols cs) {
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  const int i = bid * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double d0 = D[2 * int64_t(i)];
   if (isinf(d0)) return;                        // second of a 2x2: handled by its partner
@@ -2023,9 +2058,11 @@ template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_solve_bwd(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ lvl,
             const int32_t* __restrict__ rlist, const int32_t* __restrict__ gperm,
-            const double* __restrict__ L, double* __restrict__ xp) {
+            const double* __restrict__ L, double* __restrict__ xp, Cols cs) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const NodeDesc nd = nodes[lvl[blockIdx.x]];
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  const NodeDesc nd = nodes[lvl[bid]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = nd.n, cm = nd.m - nd.n;
   double* blk = sh;              // 64 x SB (+ 256 doubles of scratch)
@@ -2127,9 +2164,12 @@ __global__ void __launch_bounds__(256)
 k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const SolveTask* __restrict__ tasks,
                  const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
                  const double* __restrict__ L, const double* __restrict__ Linv,
-                 double* __restrict__ xp, double* __restrict__ cvec) {
+                 double* __restrict__ xp, double* __restrict__ cvec, Cols cs) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const SolveTask nd = tasks[blockIdx.x];
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  cvec += col_ * cs.scv;
+  const SolveTask nd = tasks[bid];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const int n = nd.n, m = nd.m, cm = m - n;
   double* r = sh;                         // m
@@ -2224,9 +2264,11 @@ k_solve_fwd_chol(const NodeDesc* __restrict__ nodes, const SolveTask* __restrict
 
 __global__ void __launch_bounds__(256)
 k_solve_bwd_chol(const SolveTask* __restrict__ tasks, const int32_t* __restrict__ rlist,
-                 const double* __restrict__ L, const double* __restrict__ Linv, double* __restrict__ xp) {
+                 const double* __restrict__ L, const double* __restrict__ Linv, double* __restrict__ xp, Cols cs) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const SolveTask nd = tasks[blockIdx.x];
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  const SolveTask nd = tasks[bid];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const int n = nd.n, m = nd.m;
   double* blk = sh;                        // 64 x SB tile of L, transposed access
@@ -2513,10 +2555,13 @@ template <int NMAX>   // NMAX = 32: fronts with at most 32 pivots (half the regi
 __global__ void __launch_bounds__(256)
 k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* __restrict__ gth_ptr,
                  const int64_t* __restrict__ gth_src, const int32_t* __restrict__ gperm,
-                 const double* __restrict__ L, double* __restrict__ xp, double* __restrict__ cvec) {
+                 const double* __restrict__ L, double* __restrict__ xp, double* __restrict__ cvec, Cols cs) {
   __shared__ double rsh[4][TINY_M];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ti = blockIdx.x * 4 + wave;
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  cvec += col_ * cs.scv;
+  const int ti = bid * 4 + wave;
   if (ti >= ntask) return;
   const SolveTask nd = tasks[ti];
   const int n = nd.n, m = nd.m, cm = m - n;
@@ -2555,10 +2600,12 @@ k_solve_fwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* 
 template <int NMAX>
 __global__ void __launch_bounds__(256)
 k_solve_bwd_tiny(const SolveTask* __restrict__ tasks, int ntask, const int32_t* __restrict__ rlist,
-                 const int32_t* __restrict__ gperm, const double* __restrict__ L, double* __restrict__ xp) {
+                 const int32_t* __restrict__ gperm, const double* __restrict__ L, double* __restrict__ xp, Cols cs) {
   __shared__ double zsh[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ti = blockIdx.x * 4 + wave;
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  const int ti = bid * 4 + wave;
   if (ti >= ntask) return;
   const SolveTask nd = tasks[ti];
   const int n = nd.n, m = nd.m, cm = m - n;
@@ -2600,8 +2647,12 @@ __global__ void __launch_bounds__(256)
 k_big_fwd_prep(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
                const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap,
                const int32_t* __restrict__ gperm, double* __restrict__ xp, double* __restrict__ cvec,
-               double* __restrict__ ybuf) {
-  const NodeDesc nd = nodes[list[blockIdx.x]];
+               double* __restrict__ ybuf, Cols cs) {
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  cvec += col_ * cs.scv;
+  ybuf += col_ * cs.syb;
+  const NodeDesc nd = nodes[list[bid]];
   const int tid = threadIdx.x;
   const int n = nd.n, cm = nd.m - nd.n;
   double* mine = cvec + nd.moff;
@@ -2626,8 +2677,11 @@ template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_big_store(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list,
             const int32_t* __restrict__ gperm, const double* __restrict__ ybuf,
-            double* __restrict__ xp, int load) {
-  const NodeDesc nd = nodes[list[blockIdx.x]];
+            double* __restrict__ xp, int load, Cols cs) {
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  ybuf += col_ * cs.syb;
+  const NodeDesc nd = nodes[list[bid]];
   for (int i = threadIdx.x; i < nd.n; i += 256) {
     const int g = POSDEF ? nd.sptr + i : gperm[nd.sptr + i];
     if (load) const_cast<double*>(ybuf)[nd.sptr + i] = xp[g];
@@ -2638,9 +2692,11 @@ k_big_store(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list
 template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_big_fwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ tasks, int b,
-               const double* __restrict__ L, double* __restrict__ ybuf) {
+               const double* __restrict__ L, double* __restrict__ ybuf, Cols cs) {
   __shared__ double blk[64 * SB];
-  const NodeDesc nd = nodes[tasks[blockIdx.x].node];
+  GSLS_COLS;
+  ybuf += col_ * cs.syb;
+  const NodeDesc nd = nodes[tasks[bid].node];
   const int tid = threadIdx.x, lane = tid & 63;
   const int nb = min(64, nd.n - b);
   stage_block(blk, L + nd.loff, nd.ld, b, nb, tid);
@@ -2653,9 +2709,12 @@ k_big_fwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ t
 
 __global__ void __launch_bounds__(256)
 k_big_fwd_gemv(const NodeDesc* __restrict__ nodes, const BigGemv* __restrict__ tasks, int b,
-               const double* __restrict__ L, double* __restrict__ ybuf, double* __restrict__ cvec) {
+               const double* __restrict__ L, double* __restrict__ ybuf, double* __restrict__ cvec, Cols cs) {
   __shared__ double ys[64];
-  const BigGemv t = tasks[blockIdx.x];
+  GSLS_COLS;
+  ybuf += col_ * cs.syb;
+  cvec += col_ * cs.scv;
+  const BigGemv t = tasks[bid];
   const NodeDesc nd = nodes[t.node];
   const int tid = threadIdx.x;
   const int nb = min(64, nd.n - b);
@@ -2673,10 +2732,14 @@ __global__ void __launch_bounds__(256)
 k_big_bwd_gemvT(const NodeDesc* __restrict__ nodes, const BigGemv* __restrict__ tasks, int b,
                 const int32_t* __restrict__ rlist, const double* __restrict__ L,
                 const double* __restrict__ ybuf, const double* __restrict__ xp,
-                double* __restrict__ part) {
+                double* __restrict__ part, Cols cs) {
   __shared__ double blk[64 * SB + 256];
   __shared__ double zz[64];
-  const BigGemv t = tasks[blockIdx.x];
+  GSLS_COLS;
+  ybuf += col_ * cs.syb;
+  xp += col_ * cs.sx;
+  part += col_ * cs.spt;
+  const BigGemv t = tasks[bid];
   const NodeDesc nd = nodes[t.node];
   const int tid = threadIdx.x, kc = tid & 63, q = tid >> 6;
   const int nb = min(64, nd.n - b);
@@ -2710,16 +2773,19 @@ k_big_bwd_gemvT(const NodeDesc* __restrict__ nodes, const BigGemv* __restrict__ 
   blk[64 * SB + q * 64 + kc] = s;
   __syncthreads();
   if (q == 0)
-    part[int64_t(blockIdx.x) * 64 + kc] =
+    part[int64_t(bid) * 64 + kc] =
         (blk[64 * SB + kc] + blk[64 * SB + 64 + kc]) + (blk[64 * SB + 128 + kc] + blk[64 * SB + 192 + kc]);
 }
 
 template <bool POSDEF>
 __global__ void __launch_bounds__(256)
 k_big_bwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ tasks, int b,
-               const double* __restrict__ L, double* __restrict__ ybuf, const double* __restrict__ part) {
+               const double* __restrict__ L, double* __restrict__ ybuf, const double* __restrict__ part, Cols cs) {
   __shared__ double blk[64 * SB];
-  const BigTrsv t = tasks[blockIdx.x];
+  GSLS_COLS;
+  ybuf += col_ * cs.syb;
+  part += col_ * cs.spt;
+  const BigTrsv t = tasks[bid];
   const NodeDesc nd = nodes[t.node];
   const int tid = threadIdx.x, lane = tid & 63;
   const int nb = min(64, nd.n - b);
@@ -3036,10 +3102,14 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
              const double* __restrict__ Lf, const double* __restrict__ D, const int32_t* __restrict__ gperm,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, double* __restrict__ slotv,
-             double* __restrict__ cvec) {
+             double* __restrict__ cvec, Cols cs) {
   __shared__ double accs[4][(WSLOT + 1) * 64];    // + a spare row for the masked lanes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  cvec += col_ * cs.scv;
+  if (slotv) slotv += col_ * cs.sxs;
+  const int gi = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
   if (gi >= ngroup) return;
   double* acc = accs[wave];
 #pragma unroll
@@ -3085,10 +3155,15 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
              const double* __restrict__ Lb, const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ rlist, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, const double* __restrict__ slotv,
-             double* __restrict__ xout, const double* __restrict__ scale, double* __restrict__ cvec) {
+             double* __restrict__ xout, const double* __restrict__ scale, double* __restrict__ cvec, Cols cs) {
   __shared__ double xfs[4][(WSLOT + 1) * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  cvec += col_ * cs.scv;
+  if (slotv) slotv += col_ * cs.sxs;
+  if (xout) xout += col_ * cs.sio;
+  const int gi = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
   if (gi >= ngroup) return;
   double* xfull = xfs[wave];
   const WGroup g = groups[gi];
@@ -3358,8 +3433,10 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
 // cover, when it applies D to its own fronts inside the forward step
 __global__ void __launch_bounds__(256)
 k_solve_diag_nodes(const NodeDesc* __restrict__ nodes, const int32_t* __restrict__ list, const double* __restrict__ D,
-                   const int32_t* __restrict__ gperm, double* __restrict__ xp) {
-  const NodeDesc nd = nodes[list[blockIdx.x]];
+                   const int32_t* __restrict__ gperm, double* __restrict__ xp, Cols cs) {
+  GSLS_COLS;
+  xp += col_ * cs.sx;
+  const NodeDesc nd = nodes[list[bid]];
   for (int k = threadIdx.x; k < nd.n; k += 256) {
     const int64_t i = int64_t(nd.sptr) + k;
     const double d0 = D[2 * i];
@@ -3488,6 +3565,9 @@ void dev_free(DeviceFactor& F) {
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
                   F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
   for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (void* p : {static_cast<void*>(F.mc_xp), static_cast<void*>(F.mc_xs), static_cast<void*>(F.mc_cvec),
+                  static_cast<void*>(F.mc_ybuf), static_cast<void*>(F.mc_part)})
     if (p) (void)hipFree(p);
   // the caller's matrix (gsls_set_coo) depends on the pattern only, not on the elimination order: it survives
   // the re-analyses of order repair and learning; dev_free_coo releases it
@@ -4118,7 +4198,8 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     HIPCHK(upload(F.posowner, po, st));
   }
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.ybuf), std::max(S.n, 1) * sizeof(double)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.part), std::max<int64_t>(part_max, 1) * 64 * sizeof(double)));
+  F.part_elems = std::max<int64_t>(part_max, 1) * 64;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.part), F.part_elems * sizeof(double)));
   {
     PullSeg* d1 = nullptr;
     PullTask* d2 = nullptr;
@@ -4605,7 +4686,14 @@ template <bool POSDEF>
 static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::vector<LevelPlan>& plan,
                                int job, double* xp, hipStream_t st, hipEvent_t* ev, int diag_sel = -2,
                                bool wave = false, const double* xin = nullptr, double* xout = nullptr,
-                               const double* scale = nullptr) {
+                               const double* scale = nullptr, const Cols* cols = nullptr) {
+  const Cols cs = cols ? *cols : Cols{1, 0, 0, 0, 0, 0, 0};
+  const int R = cs.R;
+  // the vectors a sweep works in: the handle's own, or (R columns at once) the first of R sets
+  double* const w_xs = R > 1 ? F.mc_xs : F.xs;
+  double* const w_cvec = R > 1 ? F.mc_cvec : F.cvec;
+  double* const w_ybuf = R > 1 ? F.mc_ybuf : F.ybuf;
+  double* const w_part = R > 1 ? F.mc_part : F.part;
   const bool do_fwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
   const bool do_diag = !POSDEF && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_DIAG ||
                                    job == GSLS_SOLVE_JOB_DIAG_BWD);
@@ -4616,13 +4704,13 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   const WGroup* wgr = static_cast<const WGroup*>(F.wgroups);
   const WTask* wtk = static_cast<const WTask*>(F.wtasks);
   const bool fuse_d = wave && do_fwd && do_diag;     // the tier applies D^-1 at the end of its forward step
-  // job ALL: the tier's forward result stays by pivot slot (F.xs) for its own backward kernels
-  double* slotv = (wave && do_fwd && do_bwd) ? F.xs : nullptr;
+  // job ALL: the tier's forward result stays by pivot slot (w_xs) for its own backward kernels
+  double* slotv = (wave && do_fwd && do_bwd) ? w_xs : nullptr;
   auto wave_fwd = [&](int g0, int cnt, bool narrow) {
     if (cnt <= 0) return;
 #define GSLS_WFWD(D_, N_)                                                                                          \
-  hipLaunchKernelGGL((k_wsolve_fwd<D_, N_>), dim3((cnt + 3) / 4), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
-                     F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, F.cvec)
+  hipLaunchKernelGGL((k_wsolve_fwd<D_, N_>), dim3(((cnt + 3) / 4) * R), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
+                     F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cs)
     if (fuse_d) { if (narrow) GSLS_WFWD(true, true); else GSLS_WFWD(true, false); }
     else { if (narrow) GSLS_WFWD(false, true); else GSLS_WFWD(false, false); }
 #undef GSLS_WFWD
@@ -4630,11 +4718,11 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   auto wave_bwd = [&](int g0, int cnt, bool narrow) {
     if (cnt <= 0) return;
     if (narrow)
-      hipLaunchKernelGGL(k_wsolve_bwd<true>, dim3((cnt + 3) / 4), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
-                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, F.cvec);
+      hipLaunchKernelGGL(k_wsolve_bwd<true>, dim3(((cnt + 3) / 4) * R), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs);
     else
-      hipLaunchKernelGGL(k_wsolve_bwd<false>, dim3((cnt + 3) / 4), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
-                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, F.cvec);
+      hipLaunchKernelGGL(k_wsolve_bwd<false>, dim3(((cnt + 3) / 4) * R), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs);
   };
   if (ev) HIPCHK(hipEventRecord(ev[0], st));
   const bool ahead = slotv != nullptr && scale == nullptr;  // the look-ahead kernels: job ALL, no user scaling
@@ -4649,46 +4737,46 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
       const LevelPlan& lp = plan[l];
       if (lp.small_cnt > 0) {
         if (POSDEF)
-          hipLaunchKernelGGL(k_solve_fwd_chol, dim3(lp.small_cnt), dim3(256),
+          hipLaunchKernelGGL(k_solve_fwd_chol, dim3(lp.small_cnt * R), dim3(256),
                              sizeof(double) * (((lp.small_maxm + 63) & ~63) + 256), st, F.nodes,
                              static_cast<const SolveTask*>(F.stasks) + lp.small_begin, F.clist, F.cmap, F.L, F.Linv,
-                             xp, F.cvec);
+                             xp, w_cvec, cs);
         else {
           const SolveTask* stk = static_cast<const SolveTask*>(F.stasks) + lp.small_begin;
           if (lp.tiny32_cnt > 0)
-            hipLaunchKernelGGL(k_solve_fwd_tiny<32>, dim3((lp.tiny32_cnt + 3) / 4), dim3(256), 0, st, stk,
-                               lp.tiny32_cnt, F.gth_ptr, F.gth_src, F.gperm, F.L, xp, F.cvec);
+            hipLaunchKernelGGL(k_solve_fwd_tiny<32>, dim3(((lp.tiny32_cnt + 3) / 4) * R), dim3(256), 0, st, stk,
+                               lp.tiny32_cnt, F.gth_ptr, F.gth_src, F.gperm, F.L, xp, w_cvec, cs);
           if (lp.tiny_cnt > lp.tiny32_cnt)
-            hipLaunchKernelGGL(k_solve_fwd_tiny<64>, dim3((lp.tiny_cnt - lp.tiny32_cnt + 3) / 4), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_solve_fwd_tiny<64>, dim3(((lp.tiny_cnt - lp.tiny32_cnt + 3) / 4) * R), dim3(256), 0, st,
                                stk + lp.tiny32_cnt, lp.tiny_cnt - lp.tiny32_cnt, F.gth_ptr, F.gth_src, F.gperm, F.L, xp,
-                               F.cvec);
+                               w_cvec, cs);
           if (lp.small_cnt > lp.tiny_cnt)
-            hipLaunchKernelGGL(k_solve_fwd<false>, dim3(lp.small_cnt - lp.tiny_cnt), dim3(256),
+            hipLaunchKernelGGL(k_solve_fwd<false>, dim3((lp.small_cnt - lp.tiny_cnt) * R), dim3(256),
                                sizeof(double) * (64 * 65 + 2 * std::max(lp.small_maxn, 1)), st, F.nodes,
-                               F.smallnodes + lp.small_begin + lp.tiny_cnt, F.clist, F.cmap, F.gperm, F.L, xp, F.cvec);
+                               F.smallnodes + lp.small_begin + lp.tiny_cnt, F.clist, F.cmap, F.gperm, F.L, xp, w_cvec, cs);
         }
       }
       if (lp.big_cnt > 0) {
-        hipLaunchKernelGGL(k_big_fwd_prep<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
-                           F.bignodes + lp.big_begin, F.clist, F.cmap, F.gperm, xp, F.cvec, F.ybuf);
+        hipLaunchKernelGGL(k_big_fwd_prep<POSDEF>, dim3((lp.big_cnt) * R), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.clist, F.cmap, F.gperm, xp, w_cvec, w_ybuf, cs);
         for (const BigStep& bs : lp.bigsteps) {
-          hipLaunchKernelGGL(k_big_fwd_trsv<POSDEF>, dim3(bs.trsv_cnt), dim3(256), 0, st, F.nodes,
-                             btr + bs.trsv_begin, bs.b, F.L, F.ybuf);
+          hipLaunchKernelGGL(k_big_fwd_trsv<POSDEF>, dim3((bs.trsv_cnt) * R), dim3(256), 0, st, F.nodes,
+                             btr + bs.trsv_begin, bs.b, F.L, w_ybuf, cs);
           if (bs.gemv_cnt > 0)
-            hipLaunchKernelGGL(k_big_fwd_gemv, dim3(bs.gemv_cnt), dim3(256), 0, st, F.nodes,
-                               bgm + bs.gemv_begin, bs.b, F.L, F.ybuf, F.cvec);
+            hipLaunchKernelGGL(k_big_fwd_gemv, dim3((bs.gemv_cnt) * R), dim3(256), 0, st, F.nodes,
+                               bgm + bs.gemv_begin, bs.b, F.L, w_ybuf, w_cvec, cs);
         }
-        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
-                           F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 0);
+        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3((lp.big_cnt) * R), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.gperm, w_ybuf, xp, 0, cs);
       }
     }
   if (ev) HIPCHK(hipEventRecord(ev[1], st));
   if (fuse_d) {
     if (F.wnont_cnt > 0)
-      hipLaunchKernelGGL(k_solve_diag_nodes, dim3(F.wnont_cnt), dim3(256), 0, st, F.nodes, F.wnont, F.D, F.gperm, xp);
+      hipLaunchKernelGGL(k_solve_diag_nodes, dim3((F.wnont_cnt) * R), dim3(256), 0, st, F.nodes, F.wnont, F.D, F.gperm, xp, cs);
   } else if (do_diag) {
     if (diag_sel == -2)
-      hipLaunchKernelGGL(k_solve_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm, xp);
+      hipLaunchKernelGGL(k_solve_diag, dim3(((S.n + 255) / 256) * R), dim3(256), 0, st, S.n, F.D, F.gperm, xp, cs);
     else
       hipLaunchKernelGGL(k_solve_diag_owned, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm,
                          F.posowner, diag_sel, xp);
@@ -4698,36 +4786,36 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
     for (int l = S.nlevels - 1; l >= 0; --l) {
       const LevelPlan& lp = plan[l];
       if (lp.big_cnt > 0) {
-        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
-                           F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 1);
+        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3((lp.big_cnt) * R), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.gperm, w_ybuf, xp, 1, cs);
         for (int k = int(lp.bigsteps.size()) - 1; k >= 0; --k) {
           const BigStep& bs = lp.bigsteps[k];
           if (bs.gemv_cnt > 0)
-            hipLaunchKernelGGL(k_big_bwd_gemvT, dim3(bs.gemv_cnt), dim3(256), 0, st, F.nodes,
-                               bgm + bs.gemv_begin, bs.b, F.rlist, F.L, F.ybuf, xp, F.part);
-          hipLaunchKernelGGL(k_big_bwd_trsv<POSDEF>, dim3(bs.trsv_cnt), dim3(256), 0, st, F.nodes,
-                             btr + bs.trsv_begin, bs.b, F.L, F.ybuf, F.part);
+            hipLaunchKernelGGL(k_big_bwd_gemvT, dim3((bs.gemv_cnt) * R), dim3(256), 0, st, F.nodes,
+                               bgm + bs.gemv_begin, bs.b, F.rlist, F.L, w_ybuf, xp, w_part, cs);
+          hipLaunchKernelGGL(k_big_bwd_trsv<POSDEF>, dim3((bs.trsv_cnt) * R), dim3(256), 0, st, F.nodes,
+                             btr + bs.trsv_begin, bs.b, F.L, w_ybuf, w_part, cs);
         }
-        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3(lp.big_cnt), dim3(256), 0, st, F.nodes,
-                           F.bignodes + lp.big_begin, F.gperm, F.ybuf, xp, 0);
+        hipLaunchKernelGGL(k_big_store<POSDEF>, dim3((lp.big_cnt) * R), dim3(256), 0, st, F.nodes,
+                           F.bignodes + lp.big_begin, F.gperm, w_ybuf, xp, 0, cs);
       }
       if (lp.small_cnt > 0) {
         if (POSDEF)
-          hipLaunchKernelGGL(k_solve_bwd_chol, dim3(lp.small_cnt), dim3(256),
+          hipLaunchKernelGGL(k_solve_bwd_chol, dim3(lp.small_cnt * R), dim3(256),
                              sizeof(double) * (64 * SB + 256 + 64 + std::max(lp.small_maxm, 1)), st,
-                             static_cast<const SolveTask*>(F.stasks) + lp.small_begin, F.rlist, F.L, F.Linv, xp);
+                             static_cast<const SolveTask*>(F.stasks) + lp.small_begin, F.rlist, F.L, F.Linv, xp, cs);
         else {
           const SolveTask* stk = static_cast<const SolveTask*>(F.stasks) + lp.small_begin;
           if (lp.small_cnt > lp.tiny_cnt)
-            hipLaunchKernelGGL(k_solve_bwd<false>, dim3(lp.small_cnt - lp.tiny_cnt), dim3(256),
+            hipLaunchKernelGGL(k_solve_bwd<false>, dim3((lp.small_cnt - lp.tiny_cnt) * R), dim3(256),
                                sizeof(double) * (64 * 65 + 256 + std::max(lp.small_maxm, 1)), st, F.nodes,
-                               F.smallnodes + lp.small_begin + lp.tiny_cnt, F.rlist, F.gperm, F.L, xp);
+                               F.smallnodes + lp.small_begin + lp.tiny_cnt, F.rlist, F.gperm, F.L, xp, cs);
           if (lp.tiny_cnt > lp.tiny32_cnt)
-            hipLaunchKernelGGL(k_solve_bwd_tiny<64>, dim3((lp.tiny_cnt - lp.tiny32_cnt + 3) / 4), dim3(256), 0, st,
-                               stk + lp.tiny32_cnt, lp.tiny_cnt - lp.tiny32_cnt, F.rlist, F.gperm, F.L, xp);
+            hipLaunchKernelGGL(k_solve_bwd_tiny<64>, dim3(((lp.tiny_cnt - lp.tiny32_cnt + 3) / 4) * R), dim3(256), 0, st,
+                               stk + lp.tiny32_cnt, lp.tiny_cnt - lp.tiny32_cnt, F.rlist, F.gperm, F.L, xp, cs);
           if (lp.tiny32_cnt > 0)
-            hipLaunchKernelGGL(k_solve_bwd_tiny<32>, dim3((lp.tiny32_cnt + 3) / 4), dim3(256), 0, st, stk,
-                               lp.tiny32_cnt, F.rlist, F.gperm, F.L, xp);
+            hipLaunchKernelGGL(k_solve_bwd_tiny<32>, dim3(((lp.tiny32_cnt + 3) / 4) * R), dim3(256), 0, st, stk,
+                               lp.tiny32_cnt, F.rlist, F.gperm, F.L, xp, cs);
         }
       }
     }
@@ -4822,26 +4910,59 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
   const bool wave = F.wave && !posdef;
   const bool has_bwd = (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD || job == GSLS_SOLVE_JOB_DIAG_BWD);
   // which side of the permutation/scaling each job touches (fkeep.F90:229-318)
-  for (int r = r0; r < nrhs; ++r) {
+  const bool scale_in = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
+  const bool scale_out = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD ||
+                                     job == GSLS_SOLVE_JOB_DIAG_BWD);
+  // the wave tier writes the solution into the caller's vector itself; the separate output permutation is only
+  // needed for the fronts it does not cover and for the jobs without a backward sweep
+  const bool fuse_out = wave && has_bwd;
+  static const int mc_env = [] { const char* e = getenv("GSLS_SOLVE_COLS"); return e ? atoi(e) : 0; }();
+  const int mc_max = (F.sharded || getenv("GSLS_NO_MULTIRHS")) ? 1
+                     : std::max(1, std::min(mc_env > 0 ? mc_env : int(DeviceFactor::MC_MAX), int(DeviceFactor::MC_MAX)));
+  for (int r = r0; r < nrhs && S.n > 0;) {
+    const int R = std::min(nrhs - r, mc_max);
     double* x = d_x + int64_t(r) * ldx;
-    if (S.n == 0) continue;
-    const bool scale_in = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_FWD);
-    const bool scale_out = d_scale && (job == GSLS_SOLVE_JOB_ALL || job == GSLS_SOLVE_JOB_BWD ||
-                                       job == GSLS_SOLVE_JOB_DIAG_BWD);
-    // the wave tier writes the solution into the caller's vector itself; the separate output permutation is only
-    // needed for the fronts it does not cover and for the jobs without a backward sweep
-    const bool fuse_out = wave && has_bwd;
-    hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
-                         scale_in ? d_scale : nullptr, F.xp);
     hipEvent_t* evr = (r == r0) ? ev : nullptr;
-    hipError_t e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, evr)
-                   : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, nullptr,
-                                                fuse_out ? x : nullptr, scale_out ? d_scale : nullptr)
-                          : solve_sweeps<false>(S, F, F.plan, job, F.xp, st, evr);
-    if (e != hipSuccess) return e;
-    if (!fuse_out || F.wnont_cnt > 0)
-      hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.xp,
-                         scale_out ? d_scale : nullptr, x);
+    hipError_t e;
+    if (R == 1) {
+      hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
+                         scale_in ? d_scale : nullptr, F.xp);
+      e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, evr)
+          : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, nullptr,
+                                       fuse_out ? x : nullptr, scale_out ? d_scale : nullptr)
+                 : solve_sweeps<false>(S, F, F.plan, job, F.xp, st, evr);
+      if (e != hipSuccess) return e;
+      if (!fuse_out || F.wnont_cnt > 0)
+        hipLaunchKernelGGL(k_permute_out, dim3(blocks), dim3(256), 0, st, S.n, F.invp, F.xp,
+                           scale_out ? d_scale : nullptr, x);
+    } else {
+      // R columns through every launch (struct Cols): the same kernels, the same bits per column.  The Cholesky path
+      // comes here only with the columns its blocked kernels could not take (fronts too tall for their LDS panel).
+      if (!F.mc_xp) {
+        constexpr int M = DeviceFactor::MC_MAX;
+        F.mc_sx = ((int64_t(S.n) + 64 + 15) / 16) * 16;
+        F.mc_scv = ((std::max<int64_t>(F.cvec_elems, 1) + 64 + 15) / 16) * 16;
+        for (double** q : {&F.mc_xp, &F.mc_xs, &F.mc_ybuf}) {
+          HIPCHK(hipMalloc(reinterpret_cast<void**>(q), M * F.mc_sx * sizeof(double)));
+          HIPCHK(hipMemsetAsync(*q, 0, M * F.mc_sx * sizeof(double), st));
+        }
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.mc_cvec), M * F.mc_scv * sizeof(double)));
+        HIPCHK(hipMemsetAsync(F.mc_cvec, 0, M * F.mc_scv * sizeof(double), st));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.mc_part), M * std::max<int64_t>(F.part_elems, 64) * sizeof(double)));
+      }
+      const Cols cs{R, F.mc_sx, F.mc_sx, F.mc_scv, F.mc_sx, std::max<int64_t>(F.part_elems, 64), int64_t(ldx)};
+      hipLaunchKernelGGL(k_permute_in_cols, dim3(blocks, R), dim3(256), 0, st, S.n, F.invp, x, int64_t(ldx),
+                         scale_in ? d_scale : nullptr, F.mc_xp, F.mc_sx);
+      e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.mc_xp, st, evr, -2, false, nullptr, nullptr, nullptr, &cs)
+          : wave ? solve_sweeps<false>(S, F, F.planW, job, F.mc_xp, st, evr, -2, true, nullptr,
+                                       fuse_out ? x : nullptr, scale_out ? d_scale : nullptr, &cs)
+                 : solve_sweeps<false>(S, F, F.plan, job, F.mc_xp, st, evr, -2, false, nullptr, nullptr, nullptr, &cs);
+      if (e != hipSuccess) return e;
+      if (!fuse_out || F.wnont_cnt > 0)
+        hipLaunchKernelGGL(k_permute_out_cols, dim3(blocks, R), dim3(256), 0, st, S.n, F.invp, F.mc_xp, F.mc_sx,
+                           scale_out ? d_scale : nullptr, x, int64_t(ldx));
+    }
+    r += R;
   }
   return hipGetLastError();
 }

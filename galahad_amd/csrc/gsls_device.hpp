@@ -98,6 +98,12 @@ struct DeviceFactor {
   double* xp_mr = nullptr;         // multi-column solves: up to 8 permuted vectors, xs_mr elements apart,
   double* cvec_mr = nullptr;       // and 8 copies of the contribution vectors, cs_mr apart
   int64_t xs_mr = 0, cs_mr = 0;
+  // several right-hand sides through one launch of the single-column kernels (struct Cols in gsls_device.hip):
+  // MC_MAX sets of work vectors, the sets mc_s* elements apart
+  static constexpr int MC_MAX = 8;
+  double *mc_xp = nullptr, *mc_xs = nullptr, *mc_cvec = nullptr, *mc_ybuf = nullptr, *mc_part = nullptr;
+  int64_t mc_sx = 0, mc_scv = 0;
+  int64_t part_elems = 0;
   std::vector<BlLevel> bl_level;
   int32_t* smallnodes = nullptr;
   void* stasks = nullptr;          // SolveTask per entry of smallnodes (same indexing)

@@ -664,6 +664,63 @@ def test_blocked_multi_rhs_equals_column_by_column(nrhs):
     s.terminate()
 
 
+@pytest.mark.parametrize("kind", ["kkt", "kkt_pivoting", "grid3d", "grid3d_chol", "scaled"])
+@pytest.mark.parametrize("nrhs", [2, 5, 9, 17])
+def test_multi_rhs_columns_in_one_launch_equal_column_by_column(kind, nrhs):
+    """Several right-hand sides on the LDL^T path go through every launch of the single-column kernels together (up to
+    eight columns: block b works on column b % R, struct Cols in gsls_device.hip; ssids_solve_mult, ssids.f90:1139-1249).
+    Every column must carry exactly the bits of a single-column solve -- whole solves and the partial solves -- with the
+    wave tier (kkt), with 2x2 pivots everywhere (kkt_pivoting), with the blocked big-front path (grid3d), on the
+    Cholesky path for fronts too tall for its own blocked multi-column kernels (grid3d_chol) and with a scaling vector
+    (scaled); repeated, so that the column sets are reused."""
+    if kind == "kkt":
+        prob = P.kkt_qpband(4000, 1500, seed=5)
+    elif kind == "kkt_pivoting":          # K = [0 B; B^T 0]: every pivot is 2x2
+        rng = np.random.default_rng(1)
+        nb = 300
+        r, cc, v = [], [], []
+        for a in range(nb):
+            for b in {a} | set(rng.integers(0, nb, 3).tolist()):
+                r.append(nb + b), cc.append(a), v.append(2.0 + rng.uniform(0, 1) if b == a else rng.uniform(-0.3, 0.3))
+        row0, col0, val0 = np.array(r), np.array(cc), np.array(v)
+        x0 = rng.uniform(-1, 1, 2 * nb)
+        prob = (2 * nb, (row0 + 1).astype(np.int32), (col0 + 1).astype(np.int32), val0,
+                P.sym_matvec(2 * nb, row0, col0, val0, x0), x0)
+    elif kind in ("grid3d", "grid3d_chol"):   # fronts of hundreds of columns: the blocked big-front path
+        prob = P.grid3d(30, 30, 30) if kind == "grid3d_chol" else P.grid3d(14, 14, 14)
+    else:
+        prob = P.kkt_qpband(3000, 1000, seed=11)
+    n, row, col, val, rhs, xs = prob
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    c.pivot_control, c.node_amalgamation, c.max_iterative_refinements = 1, 24, 0
+    if kind == "scaled":
+        c.scaling = 1
+    if kind == "grid3d_chol":
+        c.pivot_control = 2
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s.analyse(m, c, i)
+    s.factorize(m, c, i)
+    assert i.status == 0, i.gsls_inform
+    s.factorize(m, c, i)                      # the refactorization path (wave-per-front kernels, packed images)
+    assert i.status == 0
+    rng = np.random.default_rng(100 + nrhs)
+    B = np.asfortranarray(rng.uniform(-1, 1, (n, nrhs)))
+    for rep in range(2):
+        X = s.solve(m, B, c, i)
+        assert i.status == 0 and X.shape == (n, nrhs)
+        for k in range(nrhs):
+            xk = s.solve(m, B[:, k].copy(), c, i)
+            assert np.array_equal(X[:, k], xk), (rep, k)
+            assert P.scaled_residual(n, row, col, val, X[:, k], B[:, k]) <= 1e-10
+    for part in ("L", "U") if kind == "grid3d_chol" else ("L", "D", "U", "S"):
+        Y = s.part_solve(part, B, c, i)
+        for k in range(0, nrhs, 3):
+            assert np.array_equal(Y[:, k], s.part_solve(part, B[:, k].copy(), c, i)), (part, k)
+    s.terminate()
+
+
 SCALED = sorted(glob.glob(os.path.join(HERE, "golden", "scaled_*.npz")))
 
 

@@ -24,3 +24,15 @@ t1 = timed(1); t8 = timed(8)
 os.environ["GSLS_NO_MULTIRHS"] = "1"
 t8loop = timed(8)
 print("cfg2 solve: 1 rhs %.3f ms | 8 rhs blocked %.3f ms (%.2fx) | 8 rhs column by column %.3f ms" % (t1, t8, t8 / t1, t8loop))
+
+# cfg3 (KKT, LDL^T): 8 columns side by side on four streams against one after the other
+os.environ.pop("GSLS_NO_MULTIRHS")
+prob = P.kkt_qpband(1000000, 200000)
+n, row, col, val, rhs, xs = prob
+m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+s, c, i = SLS(), Control(), InformSLS(); s.initialize("gsls", c, i); c.pivot_control = 1; c.node_amalgamation = 24
+s.analyse(m, c, i); s.factorize(m, c, i); s.factorize(m, c, i); assert i.status == 0
+t1 = timed(1); t4 = timed(4); t8 = timed(8); t16 = timed(16)
+os.environ["GSLS_NO_MULTIRHS"] = "1"
+t8loop = timed(8)
+print("cfg3 solve: 1 rhs %.3f ms | 4 rhs %.3f | 8 rhs on lanes %.3f ms (%.2fx) | 16 rhs %.3f | 8 rhs column by column %.3f ms" % (t1, t4, t8, t8 / t1, t16, t8loop))
