@@ -4313,6 +4313,10 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
         if (cnt == 0 || (later > 0 && (narrow || cnt < 512))) continue;
         const TinyFrontTask* tf = static_cast<const TinyFrontTask*>(F.tftasks) + beg;
         const int tri = (maxm * (maxm + 1) / 2 + 1) & ~1;
+        static const bool dbg_launch = getenv("GSLS_DEBUG_LAUNCH") != nullptr;
+        if (dbg_launch)
+          fprintf(stderr, "[gsls] level %d: class %d, %d fronts, max m %d, LDS %zu bytes per workgroup\n", l, cls, cnt, maxm,
+                  size_t(4) * tri * 8);
 #define GSLS_FW_ARGS tf, cnt, gl, F.asrc, F.aloc, F.cur_val, F.L, F.D, F.C, F.stat, F.fastok, F.hint, \
                      F.tinyskip, F.tinyfail, small, u, F.wave ? F.Lf : nullptr, F.wave ? F.Lb : nullptr, tri, \
                      (cls <= 3 ? (F.any_hint ? 1 : 0) : 0)
