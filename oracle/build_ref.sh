@@ -126,8 +126,10 @@ if [ -f "$GSLS_LIB" ]; then
   $FC $F2 -o $OUT/sls_gsls_driver $HERE/ref_driver.f90 \
       $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
       -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
-  # SBLS above the patched SLS (source unchanged; recompiled because SLS_data_type grew)
-  $FC $F2 -c -o $W/obj2_sbls.o $S/sbls/sbls.f90
+  # SBLS above the patched SLS: SBLS_solve_explicit leaves its refinement loop to the backend (integration/patch_sbls.py;
+  # the patched copy exists only in the scratch dir)
+  python3 $HERE/../integration/patch_sbls.py $S/sbls/sbls.f90 $W/sbls_gsls.f90
+  $FC $F2 -c -o $W/obj2_sbls.o $W/sbls_gsls.f90
   $FC $F2 -o $OUT/sbls_gsls_driver $HERE/sbls_driver.f90 $W/obj2_sbls.o \
       $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
       -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++

@@ -1,6 +1,7 @@
 """SBLS row of the scope table: the reference's SBLS_form_and_factorize / SBLS_solve
-(src/sbls/sbls.f90:1695-1903, 4937-5388) -- unchanged source, built above the patched SLS facade --
-with control%symmetric_linear_solver = 'gsls'.  SBLS assembles K = [H A^T; A -C] in COORDINATE form,
+(src/sbls/sbls.f90:1695-1903, 4937-5388), built above the patched SLS facade with
+control%symmetric_linear_solver = 'gsls'; the only change to SBLS is that SBLS_solve_explicit hands its refinement loop
+to the backend (integration/patch_sbls.py: one SLS_solve with max_iterative_refinements = itref_max, on the device).  SBLS assembles K = [H A^T; A -C] in COORDINATE form,
 analyses/factorizes through SLS, checks the inertia itself (exactly m negative eigenvalues,
 sbls.f90:4166-4224) and refines the solve; all of that is the reference's own Fortran, only the
 factorize+solve underneath runs on the MI355X.
@@ -92,6 +93,31 @@ def test_sbls_kkt_constructed_solution(n, m):
 
 
 @pytest.mark.gpu
+def test_sbls_refinement_runs_in_the_backend():
+    """SBLS_solve_explicit's loop (sbls.f90:5147-5380: solve, update, residual over K on the host, itref_max times) is one
+    SLS_solve with max_iterative_refinements = itref_max for 'gsls' (integration/patch_sbls.py).  Same recurrence:
+    on a KKT system whose H spans eight decades the residual of the returned solution falls with itref_max exactly as
+    refinement steps make it fall, and itref_max = 0 is the plain solve."""
+    refio = _need()
+    n, m = 20000, 6000
+    H, A, C = _qp_kkt(n, m, 5)
+    rng = np.random.default_rng(11)
+    x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, m)
+    rhs = _kkt_rhs(n, m, H, A, x, y)
+    scale = np.abs(rhs).max()
+    res, err = [], []
+    for it in (0, 1, 3):
+        r = refio.run_sbls(n, m, H, A, C, rhs, solver="gsls", factorization=2, itref_max=it)
+        assert (r["status_factorize"], r["status_solve"]) == (0, 0)
+        sol = r["sol"]
+        res.append(np.abs(_kkt_rhs(n, m, H, A, sol[:n], sol[n:]) - rhs).max() / scale)
+        err.append(np.abs(sol - np.concatenate([x, y])).max())
+    assert res[0] <= 1e-9 and res[1] <= 1e-14 and res[2] <= 1e-14, res
+    assert res[1] < 0.1 * res[0] or res[0] <= 1e-15, res          # one refinement step gains at least a digit
+    assert err[2] <= 1e-8, err
+
+
+@pytest.mark.gpu
 def test_sbls_cfg3_full_size():
     """BASELINE.json configs[2]: SBLS KKT saddle point of a synthetic QP, n = 1e6, m = 2e5, through the
     real SBLS; three form_and_factorize + solve rounds (new values, same structure) as CQP would do."""
@@ -104,8 +130,8 @@ def test_sbls_cfg3_full_size():
     assert (r["status_factorize"], r["status_solve"]) == (0, 0)
     assert r["negative_eigenvalues"] == m
     assert np.abs(r["sol"] - 1.0).max() <= 1e-7
-    print("cfg3 through SBLS: factorize median %.3f s, solve median %.3f s" % (
-        r["t_factorize_median"], r["t_solve_median"]))
+    print("cfg3 through SBLS: form_and_factorize median %.2f ms, solve median %.2f ms" % (
+        1e3 * r["t_factorize_median"], 1e3 * r["t_solve_median"]))
 
 
 @pytest.mark.gpu
