@@ -1834,17 +1834,34 @@ k_contrib_tiny(const TinyContribTask* __restrict__ tasks, int ntask, const doubl
   }
 }
 
-// Several right-hand sides through ONE launch of a solve kernel: the grid is R times as long, block b works on column
-// b % R of task b / R (the R columns of a front next to each other in dispatch order: L comes from HBM once and from
-// the caches R - 1 times, and a sweep that is bound by latency gets R times the waves in flight).  The columns'
+// Several right-hand sides through ONE launch of a solve kernel: the grid is R times as long and every task is done
+// once per column (a sweep that is bound by latency gets R times the waves in flight).  Workgroup b runs on XCD b % 8:
+// the R columns of a task are given to workgroups of the SAME XCD, eight dispatch slots apart (a round of 8 R
+// workgroups = 8 tasks x R columns), so that L comes from HBM once and from that XCD's L2 R - 1 times.  The columns'
 // work vectors lie at fixed strides; R = 1: one column, strides unused.
 struct Cols {
-  int R;
+  int R, xcd;                            // xcd = 0: plain mapping (column b % R of task b / R)
   int64_t sx, sxs, scv, syb, spt, sio;   // xp, slot vector, contribution vectors, ybuf, part, the caller's columns
 };
-#define GSLS_COLS                                                          \
-  const int col_ = cs.R > 1 ? int(blockIdx.x % unsigned(cs.R)) : 0;        \
-  const unsigned bid = cs.R > 1 ? blockIdx.x / unsigned(cs.R) : blockIdx.x
+__device__ __forceinline__ void cols_map(const Cols& cs, int& col, unsigned& bid) {
+  const unsigned b = blockIdx.x, R = unsigned(cs.R);
+  if (cs.R <= 1) { col = 0; bid = b; return; }
+  if (!cs.xcd) { col = int(b % R); bid = b / R; return; }
+  const unsigned nb = gridDim.x / R, full = nb & ~7u, base = full * R;
+  if (b < base) {
+    const unsigned q = b / (8 * R), r = b % (8 * R);
+    col = int(r >> 3);
+    bid = q * 8 + (r & 7);
+  } else {                               // the last, incomplete round
+    const unsigned rem = nb - full, r = b - base;
+    col = int(r / rem);
+    bid = full + r % rem;
+  }
+}
+#define GSLS_COLS      \
+  int col_;            \
+  unsigned bid;        \
+  cols_map(cs, col_, bid)
 
 // permutation kernels for R columns at once: grid (blocks, R)
 __global__ void k_permute_in_cols(int n, const int32_t* __restrict__ invp, const double* __restrict__ x, int64_t ldx,
@@ -4691,7 +4708,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
                                int job, double* xp, hipStream_t st, hipEvent_t* ev, int diag_sel = -2,
                                bool wave = false, const double* xin = nullptr, double* xout = nullptr,
                                const double* scale = nullptr, const Cols* cols = nullptr) {
-  const Cols cs = cols ? *cols : Cols{1, 0, 0, 0, 0, 0, 0};
+  const Cols cs = cols ? *cols : Cols{1, 0, 0, 0, 0, 0, 0, 0};
   const int R = cs.R;
   // the vectors a sweep works in: the handle's own, or (R columns at once) the first of R sets
   double* const w_xs = R > 1 ? F.mc_xs : F.xs;
@@ -4954,7 +4971,8 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
         HIPCHK(hipMemsetAsync(F.mc_cvec, 0, M * F.mc_scv * sizeof(double), st));
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.mc_part), M * std::max<int64_t>(F.part_elems, 64) * sizeof(double)));
       }
-      const Cols cs{R, F.mc_sx, F.mc_sx, F.mc_scv, F.mc_sx, std::max<int64_t>(F.part_elems, 64), int64_t(ldx)};
+      static const int cols_xcd = getenv("GSLS_COLS_XCD") ? atoi(getenv("GSLS_COLS_XCD")) : 1;
+      const Cols cs{R, cols_xcd, F.mc_sx, F.mc_sx, F.mc_scv, F.mc_sx, std::max<int64_t>(F.part_elems, 64), int64_t(ldx)};
       hipLaunchKernelGGL(k_permute_in_cols, dim3(blocks, R), dim3(256), 0, st, S.n, F.invp, x, int64_t(ldx),
                          scale_in ? d_scale : nullptr, F.mc_xp, F.mc_sx);
       e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.mc_xp, st, evr, -2, false, nullptr, nullptr, nullptr, &cs)
