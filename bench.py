@@ -152,7 +152,8 @@ def facade_timings(prob, a, nemin):
             out["sbls"] = {"form_and_factorize_ms": rs["t_factorize_median"] * 1e3, "solve_ms": rs["t_solve_median"] * 1e3,
                            "status": [rs["status_factorize"], rs["status_solve"]],
                            "max_err": float(np.abs(rs["sol"] - xs).max()),
-                           "note": "SBLS_solve refines with its own host loops over K (src/sbls/sbls.f90:5343-5372)"}
+                           "note": "SBLS_solve_explicit (src/sbls/sbls.f90:5073-5388) with its refinement loop handed to the backend "
+                                   "(integration/patch_sbls.py); K is assembled on the host"}
     except Exception as e:      # the facade run is a report, not the metric
         out["error"] = repr(e)[:200]
     return out

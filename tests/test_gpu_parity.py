@@ -721,6 +721,35 @@ def test_multi_rhs_columns_in_one_launch_equal_column_by_column(kind, nrhs):
     s.terminate()
 
 
+@pytest.mark.parametrize("posdef", [False, True])
+def test_multi_rhs_with_padded_leading_dimension(posdef):
+    """gsls_solve / gsls_solve_dev take X(ldx, nrhs) with ldx >= n (ssids_solve_mult's ldx, ssids.f90:1139-1160): columns
+    ldx apart, the rows from n on untouched -- on the host entry point and on the device one."""
+    import ctypes as C
+    import torch
+    from galahad_amd._lib import lib, Inform
+    prob = P.banded_spd(3000, 21, seed=4) if posdef else P.kkt_qpband(2500, 900, seed=9)
+    n, row, col, val, rhs, xs = prob
+    s, m, c, i = run_gsls(prob, posdef, nemin=24, ordering_free=True)
+    assert i.status == 0
+    c.max_iterative_refinements = 0
+    nrhs, ldx = 11, n + 37
+    rng = np.random.default_rng(3)
+    B = rng.uniform(-1, 1, (nrhs, ldx))                  # row k = column k of the Fortran array X(ldx, nrhs)
+    ref = np.stack([s.solve(m, B[k, :n].copy(), c, i) for k in range(nrhs)])
+    inf = Inform()
+    X = B.copy()
+    f = lib.gsls_solve(s.handle, 0, nrhs, C.c_void_p(X.ctypes.data), ldx, C.byref(s.opts), C.byref(inf))
+    assert f >= 0
+    assert np.array_equal(X[:, :n], ref) and np.array_equal(X[:, n:], B[:, n:])
+    Xd = torch.from_numpy(B.copy()).cuda()
+    f = lib.gsls_solve_dev(s.handle, 0, nrhs, C.c_void_p(Xd.data_ptr()), ldx, C.byref(s.opts), C.byref(inf))
+    assert f >= 0
+    Xh = Xd.cpu().numpy()
+    assert np.array_equal(Xh[:, :n], ref) and np.array_equal(Xh[:, n:], B[:, n:])
+    s.terminate()
+
+
 SCALED = sorted(glob.glob(os.path.join(HERE, "golden", "scaled_*.npz")))
 
 
