@@ -76,6 +76,8 @@ def main():
     bad = 0; skipped = 0
     only = int(os.environ.get("SOAK_ONLY", "-1"))
     for it in range(N):
+        if it % 50 == 49:
+            print("... %d of %d systems, %d failures so far" % (it + 1, N, bad), flush=True)   # (a silent run looks hung)
         kind = ["spd", "indef", "saddle", "weakdiag", "ipm"][it % 5] if os.environ.get("SOAK_IPM") else ["spd", "indef", "saddle", "weakdiag"][it % 4]
         n = int(rng.integers(300, 2500)) if os.environ.get("SOAK_BIG") else int(rng.integers(5, 260))
         if os.environ.get("SOAK_WIDE"):          # wide fronts: dense / banded / arrow
@@ -127,10 +129,21 @@ def main():
             s.factorize(m, ctl, i)
             ok = i.status == 0
             if ok:
-                if it % 7 == 3:           # several right-hand sides at once
-                    X = s.solve(m, np.column_stack([rhs, 2 * rhs, -rhs]), ctl, i)
-                    lin = max(np.abs(X[:, 1] - 2 * X[:, 0]).max(), np.abs(X[:, 2] + X[:, 0]).max())
-                    x = X[:, 0] if lin <= 1e-9 * max(1.0, np.abs(X).max()) else X[:, 0] * np.nan
+                if it % 7 == 3:           # several right-hand sides at once (3, or 2..17 with random columns)
+                    if it % 14 == 3:
+                        X = s.solve(m, np.column_stack([rhs, 2 * rhs, -rhs]), ctl, i)
+                        lin = max(np.abs(X[:, 1] - 2 * X[:, 0]).max(), np.abs(X[:, 2] + X[:, 0]).max())
+                        x = X[:, 0] if lin <= 1e-9 * max(1.0, np.abs(X).max()) else X[:, 0] * np.nan
+                    else:                 # every column must carry the bits of a single-column solve
+                        r2 = np.random.default_rng(1000 + it)
+                        k = int(r2.integers(2, 18))
+                        Bm = np.asfortranarray(np.column_stack([rhs] + [r2.uniform(-1, 1, n) for _ in range(k - 1)]))
+                        X = s.solve(m, Bm, ctl, i)
+                        j = int(r2.integers(1, k))
+                        same = ctl.max_iterative_refinements > 0 or \
+                            (np.array_equal(X[:, j], s.solve(m, Bm[:, j].copy(), ctl, i)) and
+                             np.array_equal(X[:, 0], s.solve(m, rhs.copy(), ctl, i)))
+                        x = X[:, 0] if same else X[:, 0] * np.nan
                 else:
                     x = s.solve(m, rhs, ctl, i)
                 err = np.abs(x - xd).max() / max(1.0, np.abs(xd).max())
