@@ -187,7 +187,10 @@ int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double resid
 
 /* replaces ssids_solve(x, ...) / ssids_solve(nrhs, x, ldx, ..., job)
  *          src/ssids/ssids.f90:1114-1249 (called from SLS_solve_one_rhs / SLS_solve_multiple_rhs,
- *          src/sls/sls.f90:5392-5397, 5693-5700; SLS_part_solve, sls.f90:6886-6920). */
+ *          src/sls/sls.f90:5392-5397, 5693-5700; SLS_part_solve, sls.f90:6886-6920).
+ * x is X(ldx, nrhs) column-major, ldx >= n; rows n..ldx-1 are not touched.  Several columns go through the kernels
+ * together (Cholesky: blocks of 8/4/2 columns in one pass over L; otherwise up to 8 columns per launch) and every
+ * column carries exactly the bits a call with nrhs = 1 gives it. */
 int gsls_solve(void* handle, int32_t job, int32_t nrhs, double* x, int32_t ldx,
                const gsls_options* options, gsls_inform* inform);
 
