@@ -145,6 +145,90 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
   }
 }
 
+// ---- tiles in MFMA layout, the shared A operand through a 20-entry LDS table that one lane writes (no selects) ----
+template <int REP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_tiles_lds(const double* __restrict__ A, double* __restrict__ Lo, double* __restrict__ Do, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = blockIdx.x * 4 + wave;
+  if (f >= N) return;
+  const int li = lane >> 4, lb = (lane >> 2) & 3, lj = lane & 3;
+  __shared__ __attribute__((aligned(16))) double tabs[4][24];   // per wave: M(i, k) at [4 k + i], d_k at [16 + k]
+  double* tab = tabs[wave];
+  if (lane < 24) tab[lane] = 0.0;
+  double R[8][2], dsave[8] = {0, 0, 0, 0, 0, 0, 0, 0}, chk = 0.0;   // dsave[p]: lane k < 4 holds pivot 4 p + k
+  for (int rep = 0; rep < REP; ++rep) {
+    const double* a = A + size_t((f + rep) & 63) * 1024;
+#pragma unroll
+    for (int J = 0; J < 8; ++J)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = 4 * (4 * h + lb) + lj, col = 4 * J + li;
+        R[J][h] = ((row >= col) ? a[col * 32 + row] : a[row * 32 + col]);
+      }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int hp = p >> 2, bp = p & 3;
+      const double T = R[p][hp];
+      // the diagonal tile, lower triangle: element (r, c) of the tile sits at lane 16 c + 4 bp + r
+      const double t00 = readlane_f64(T, 4 * bp + 0), t10 = readlane_f64(T, 4 * bp + 1), t20 = readlane_f64(T, 4 * bp + 2),
+                   t30 = readlane_f64(T, 4 * bp + 3), t11 = readlane_f64(T, 16 + 4 * bp + 1), t21 = readlane_f64(T, 16 + 4 * bp + 2),
+                   t31 = readlane_f64(T, 16 + 4 * bp + 3), t22 = readlane_f64(T, 32 + 4 * bp + 2), t32 = readlane_f64(T, 32 + 4 * bp + 3),
+                   t33 = readlane_f64(T, 48 + 4 * bp + 3);
+      // scalar LDL^T of the 4 x 4 tile (wave-uniform values)
+      const double d0 = t00, r0 = inv_f64(d0);
+      const double l10 = t10 * r0, l20 = t20 * r0, l30 = t30 * r0;
+      const double d1 = fma(-l10, t10, t11), r1 = inv_f64(d1);
+      const double u21 = fma(-l20, t10, t21), u31 = fma(-l30, t10, t31);
+      const double l21 = u21 * r1, l31 = u31 * r1;
+      const double d2 = fma(-l21, u21, fma(-l20, t20, t22)), r2 = inv_f64(d2);
+      const double u32 = fma(-l31, u21, fma(-l30, t20, t32));
+      const double l32 = u32 * r2;
+      const double d3 = fma(-l32, u32, fma(-l31, u31, fma(-l30, t30, t33))), r3 = inv_f64(d3);
+      // inverse of the unit lower factor, M = D^-1 L^-1
+      const double i10 = -l10, i21 = -l21, i32 = -l32;
+      const double i20 = fma(-l21, i10, -l20), i31 = fma(-l32, i21, -l31);
+      const double i30 = fma(-l32, i20, fma(-l31, i10, -l30));
+      // A operand of the panel solve: lane 16 k + 4 b + i holds M(i, k)   (i = lj, k = li): through the table
+      if (lane == 0) {
+        tab[0] = r0; tab[1] = i10 * r1; tab[2] = i20 * r2; tab[3] = i30 * r3;
+        tab[5] = r1; tab[6] = i21 * r2; tab[7] = i31 * r3;
+        tab[10] = r2; tab[11] = i32 * r3;
+        tab[15] = r3;
+        tab[16] = d0; tab[17] = d1; tab[18] = d2; tab[19] = d3;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double Mop = tab[4 * li + lj];
+      const double dk = tab[16 + li];
+      __builtin_amdgcn_wave_barrier();
+      dsave[p] = tab[16 + (lane & 3)];
+      // panel: (L_Ip)^T = M (F_Ip)^T for the row tiles of tile column p (those above the diagonal come out as by-products)
+#pragma unroll
+      for (int h = hp; h < 2; ++h) R[p][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(Mop, R[p][h], 0.0, 0, 0, 0);
+      // trailing update, tile column by tile column: R[J][h] -= (W_Jp)(L_Ip)^T transposed, W = L D
+#pragma unroll
+      for (int J = p + 1; J < 8; ++J) {
+        const int hJ = J >> 2, bJ = J & 3;
+        const double Aop = -bperm_f64(R[p][hJ], (lane & 0x33) | (bJ << 2)) * dk;
+#pragma unroll
+        for (int h = hJ; h < 2; ++h) R[J][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(Aop, R[p][h], R[J][h], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int J = 0; J < 8; ++J) chk += R[J][0] + R[J][1] + dsave[J];
+  }
+#pragma unroll
+  for (int J = 0; J < 8; ++J)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 4 * (4 * h + lb) + lj, col = 4 * J + li;
+      if (row > col) Lo[size_t(f) * 1024 + col * 32 + row] = R[J][h];
+    }
+  if (lane < 4) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) Do[size_t(f) * 32 + 4 * p + lane] = dsave[p] + ((chk == 12345.678) ? 1.0 : 0.0);
+  }
+}
+
 static void cpu_ldlt(const double* a, std::vector<double>& L, std::vector<double>& D) {
   std::vector<double> w(a, a + 1024);
   L.assign(1024, 0.0); D.assign(32, 0.0);
@@ -205,6 +289,7 @@ int main() {
   CHK(hipMemcpy(dA, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
   const double t1 = run(k_rows<REP>, "rows", dA, dL, dD, N, REP, hA);
   const double t2 = run(k_tiles<REP>, "tiles", dA, dL, dD, N, REP, hA);
-  printf("tiles / rows = %.2f\n", t2 / t1);
+  const double t3 = run(k_tiles_lds<REP>, "tiles+lds", dA, dL, dD, N, REP, hA);
+  printf("tiles / rows = %.2f, tiles with the LDS table / rows = %.2f\n", t2 / t1, t3 / t1);
   return 0;
 }
