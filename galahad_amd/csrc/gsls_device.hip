@@ -3141,14 +3141,40 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
     // hop behind the previous front's last instruction.
     int ti = g.tbeg;
     WTask ta = wave_task(tasks, ti);
+#ifdef GSLS_STAMPS   // where a wave's time goes, summed over the launch (100 MHz ticks): g_stamps[32..36]
+    unsigned long long pht = __builtin_amdgcn_s_memrealtime(), ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, nfr = 0;
+#define WPH(x) do { const unsigned long long t__ = __builtin_amdgcn_s_memrealtime(); x += t__ - pht; pht = t__; } while (0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WPH(ph3);                             // group record + first task record
+#else
+#define WPH(x) do {} while (0)
+#endif
     while (true) {
       const WTask tb = wave_task(tasks, min(ti + 1, te - 1));
       WFwdPre<32> A;
       wave_fwd_load<32, APPLY_D>(ta, lane, A, Lf, D, gperm, cmap, xp);
+#ifdef GSLS_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WPH(ph0);                           // image, right-hand side, D, maps: issue -> arrival
+      ++nfr;
+#endif
       wave_fwd_compute<32, APPLY_D, false>(ta, lane, A, acc, gth_ptr, gth_src, xp, slotv, cvec);
+#ifdef GSLS_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WPH(ph1);                           // recurrence, LDS hand-off, stores issued (and the next task record arrived)
+#endif
       if (++ti >= te) break;
       ta = tb;
     }
+#ifdef GSLS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WPH(ph2);                             // the last stores
+    if (lane == 0) {
+      atomicAdd(&g_stamps[32], ph0); atomicAdd(&g_stamps[33], ph1); atomicAdd(&g_stamps[34], ph2);
+      atomicAdd(&g_stamps[35], ph3); atomicAdd(&g_stamps[36], nfr); atomicAdd(&g_stamps[37], 1ull);
+    }
+#endif
+#undef WPH
   } else {
     for (int ti = g.tbeg; ti < te; ++ti) {
       const WTask t = wave_task(tasks, ti);
