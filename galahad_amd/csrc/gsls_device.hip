@@ -4043,49 +4043,19 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
           wp[ti] = WPack{S.loff[s], s, 0};
         }
       }
-      // The images in the order the waves of a launch reach them, not run by run: the k-th fronts of all runs of a launch
-      // lie next to each other (forward image; backward image: the k-th from the end).  Thousands of waves each streaming
-      // their own 25 KB run leave every DRAM row after one 256-byte piece; with this order the waves that run together
-      // read neighbouring memory, as a streaming kernel does.
+      // images and gather lists in launch order (run by run; laying the images out in the order the waves of a launch
+      // reach them -- the k-th fronts of all runs next to each other -- was measured: no difference)
       int64_t of = 0, ob = 0;
-      std::vector<int64_t> lfo(nT, 0), lbo(nT, 0);
-      {
-        static const int img_order = getenv("GSLS_IMG_ORDER") ? atoi(getenv("GSLS_IMG_ORDER")) : 0;   // (opt-in until it has been through the whole suite)
-        if (!img_order) {
-          for (int64_t ti = 0; ti < nT; ++ti) {
-            lfo[ti] = of;
-            lbo[ti] = ob;
-            of += wf_size(wt[ti].m, wt[ti].n);
-            ob += wb_size(wt[ti].m, wt[ti].n);
-          }
-        } else {
-          for (int sg = 0; sg < nstage; ++sg) {
-            const int b0 = F.wstage_begin[sg], nar = F.wstage_narrow[sg], cnt = F.wstage_cnt[sg];
-            const int rb[3] = {b0, b0 + nar, b0 + cnt};
-            for (int part = 0; part < 2; ++part) {            // the narrow launch, then the wide one
-              int maxlen = 0;
-              for (int r = rb[part]; r < rb[part + 1]; ++r) maxlen = std::max(maxlen, int(wg[r].tcnt));
-              for (int k = 0; k < maxlen; ++k)
-                for (int r = rb[part]; r < rb[part + 1]; ++r) {
-                  if (wg[r].tcnt <= k) continue;
-                  const int64_t tf = int64_t(wg[r].tbeg) + k, tbk = int64_t(wg[r].tbeg) + wg[r].tcnt - 1 - k;
-                  lfo[tf] = of;
-                  of += wf_size(wt[tf].m, wt[tf].n);
-                  lbo[tbk] = ob;
-                  ob += wb_size(wt[tbk].m, wt[tbk].n);
-                }
-            }
-          }
-        }
-      }
       std::vector<int64_t> nlf(nn, -1), nlb(nn, -1);
       for (int64_t ti = 0; ti < nT; ++ti) {
         WTask& t = wt[ti];
         const int s = wp[ti].node, pm = t.m;
-        t.lfoff = lfo[ti];
-        t.lboff = lbo[ti];
-        nlf[s] = lfo[ti];
-        nlb[s] = lbo[ti];
+        t.lfoff = of;
+        t.lboff = ob;
+        nlf[s] = of;
+        nlb[s] = ob;
+        of += wf_size(t.m, t.n);
+        ob += wb_size(t.m, t.n);
         if (!(t.flags & WT_PULL)) continue;
         t.goff = int64_t(gptr.size()) - 1;
         std::vector<std::vector<int64_t>> rows(pm);
