@@ -35,4 +35,4 @@ s.analyse(m, c, i); s.factorize(m, c, i); s.factorize(m, c, i); assert i.status 
 t1 = timed(1); t4 = timed(4); t8 = timed(8); t16 = timed(16)
 os.environ["GSLS_NO_MULTIRHS"] = "1"
 t8loop = timed(8)
-print("cfg3 solve: 1 rhs %.3f ms | 4 rhs %.3f | 8 rhs on lanes %.3f ms (%.2fx) | 16 rhs %.3f | 8 rhs column by column %.3f ms" % (t1, t4, t8, t8 / t1, t16, t8loop))
+print("cfg3 solve: 1 rhs %.3f ms | 4 rhs %.3f | 8 rhs in one launch %.3f ms (%.2fx) | 16 rhs %.3f | 8 rhs column by column %.3f ms" % (t1, t4, t8, t8 / t1, t16, t8loop))
