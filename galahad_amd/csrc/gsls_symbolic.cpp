@@ -15,6 +15,9 @@
 //   src/ssids/anal.f90:1129-1231  build_map (A entry -> position in front)
 //   src/ssids/anal.f90:37-80      expand_pattern, :147-197 check_order
 // It is written from that behaviour, 0-based, on std::vector; integer-only, O(nnz alpha(n)).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -247,10 +250,19 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
   S.n = n;
   if (nemin < 1) nemin = 32;
   int flag = GSLS_SUCCESS;
+  static const bool dbg_time = getenv("GSLS_DEBUG") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg_time) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[gsls] analyse: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
 
   std::vector<int64_t> aptr;
   std::vector<int> arow;
   expand_lower(n, ptr, row, aptr, arow);
+  lap("expand pattern");
 
   // ---- pivot order ---------------------------------------------------------------------------
   S.perm.assign(n, 0);
@@ -272,6 +284,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
       order_nested_dissection(n, aptr, arow, S.perm);
     for (int i = 0; i < n; ++i) S.invp[S.perm[i]] = i;
   }
+  lap("ordering");
 
   // ---- tree, counts, supernodes -----------------------------------------------------------------
   std::vector<int> parent, cc;
@@ -279,6 +292,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
   postorder(n, aptr, S.perm, S.invp, parent, S.realn);
   if (S.realn != n) flag = GSLS_WARNING_ANAL_SINGULAR;
   column_counts(n, aptr, arow, S.perm, S.invp, parent, cc);
+  lap("tree, postorder, counts");
   Supernodes sn;
   std::vector<char> forcecol;
   if (force_var) {
@@ -298,6 +312,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
   S.sparent = sn.sparent;
   const int nn = S.nnodes;
 
+  lap("supernodes");
   // ---- row lists: own pivots + what the children pass up + new rows from A, then sorted ---------
   S.rptr.assign(nn + 1, 0);
   for (int s = 0; s < nn; ++s) S.rptr[s + 1] = S.rptr[s] + sn.scc[s];
@@ -458,6 +473,7 @@ int symbolic_analyse(int n, const int64_t* ptr, const int32_t* row, int32_t* ord
     S.loff[s + 1] = S.loff[s] + int64_t(S.ldl[s]) * ne;
   }
   layout_contrib_auto(S);
+  lap("row lists, maps, layout");
   return flag;
 }
 
