@@ -14,8 +14,11 @@
 //   leaves are numbered in breadth-first order (a reverse Cuthill-McKee flavour: small bandwidth,
 //   so leaf fronts stay narrow).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <new>
 #include <numeric>
+#include <thread>
 
 #include "gsls_internal.hpp"
 
@@ -70,34 +73,35 @@ int degree_in(const Work& w, int id, int v) {
 
 }  // namespace
 
-void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow,
-                             std::vector<int>& perm) {
-  perm.assign(n, -1);
-  if (n == 0) return;
-  Work w(aptr, arow, n);
-  int leaf_size = 128;
-  if (const char* e = std::getenv("GSLS_ND_LEAF")) leaf_size = std::max(8, std::atoi(e));   // tuning knob
+namespace {
 
-  struct Sub {
-    std::vector<int> verts;
-    int hi;  // positions [hi - verts.size(), hi) belong to this subproblem
-  };
-  std::vector<Sub> stack;
-  {
-    Sub all;
-    all.verts.resize(n);
-    std::iota(all.verts.begin(), all.verts.end(), 0);
-    all.hi = n;
-    stack.push_back(std::move(all));
-  }
+struct Sub {
+  std::vector<int> verts;
+  int hi;  // positions [hi - verts.size(), hi) belong to this subproblem
+};
+
+// Scratch of one worker: the search arrays (indexed by vertex; a worker only ever touches the vertices of its own
+// subproblems, and a vertex outside them reads as "not mine") and the id counter that goes with them.
+struct Dissector {
+  Work w;
   int next_id = 0;
   std::vector<int> order, lptr, order2, lptr2;
-  while (!stack.empty()) {
+  Dissector(const std::vector<int64_t>& a, const std::vector<int>& r, int n) : w(a, r, n) {}
+};
+
+// One step: take a subproblem off the stack, number it (leaf) or cut it and push the pieces.  What a subproblem gets
+// depends on its vertices and the graph only -- not on the order in which subproblems are taken, nor on who takes them.
+void dissect_one(Dissector& d, std::vector<Sub>& stack, std::vector<int>& perm, int leaf_size) {
+  Work& w = d.w;
+  std::vector<int>&order = d.order, &lptr = d.lptr, &order2 = d.order2, &lptr2 = d.lptr2;
+  const std::vector<int64_t>& aptr = w.ap;
+  const std::vector<int>& arow = w.ar;
+  {
     Sub sub = std::move(stack.back());
     stack.pop_back();
-    const int id = next_id++;
+    const int id = d.next_id++;
     const int cnt = int(sub.verts.size());
-    if (cnt == 0) continue;
+    if (cnt == 0) return;
     for (int v : sub.verts) w.tag[v] = id;
 
     // connected component of the first vertex; anything unreached becomes its own subproblem
@@ -109,7 +113,7 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
       rest.hi = sub.hi - int(comp.verts.size());
       stack.push_back(std::move(rest));
       stack.push_back(std::move(comp));
-      continue;
+      return;
     }
     // pseudo-peripheral root: restart from a minimum-degree vertex of the last level while the
     // level structure keeps getting deeper
@@ -175,7 +179,7 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
       // breadth-first numbering, deepest level first so the root of the search is eliminated last
       int pos = sub.hi - cnt;
       for (int i = cnt - 1; i >= 0; --i) perm[order[i]] = pos++;
-      continue;
+      return;
     }
     // separator = vertices of level jsep with a neighbour in level jsep+1
     Sub left, right;
@@ -199,6 +203,72 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
     stack.push_back(std::move(left));
     stack.push_back(std::move(right));
   }
+}
+
+}  // namespace
+
+void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std::vector<int>& arow,
+                             std::vector<int>& perm) {
+  perm.assign(n, -1);
+  if (n == 0) return;
+  int leaf_size = 128;
+  if (const char* e = std::getenv("GSLS_ND_LEAF")) leaf_size = std::max(8, std::atoi(e));   // tuning knob
+  int nthreads = int(std::min(4u, std::max(1u, std::thread::hardware_concurrency())));   // (the top cut is sequential: more do not pay)
+  if (const char* e = std::getenv("GSLS_ND_THREADS")) nthreads = std::max(1, std::atoi(e));
+  if (n < 200000) nthreads = 1;
+
+  std::vector<Sub> stack;
+  {
+    Sub all;
+    all.verts.resize(n);
+    std::iota(all.verts.begin(), all.verts.end(), 0);
+    all.hi = n;
+    stack.push_back(std::move(all));
+  }
+  Dissector d0(aptr, arow, n);
+  if (nthreads == 1) {
+    while (!stack.empty()) dissect_one(d0, stack, perm, leaf_size);
+    return;
+  }
+  // The top of the dissection tree on this thread, always the largest pending subproblem first, until there are enough
+  // pieces to share out; then every worker takes pieces (largest first, from a common counter) and finishes each of
+  // them on a stack and scratch arrays of its own.  The result is the one-thread result, whatever the schedule.
+  const size_t want = size_t(nthreads) * 8;
+  while (!stack.empty() && stack.size() < want) {
+    size_t big = 0;
+    for (size_t k = 1; k < stack.size(); ++k)
+      if (stack[k].verts.size() > stack[big].verts.size()) big = k;
+    if (stack[big].verts.size() <= size_t(std::max(leaf_size, 4096))) break;
+    std::swap(stack[big], stack.back());
+    dissect_one(d0, stack, perm, leaf_size);
+  }
+  std::sort(stack.begin(), stack.end(), [](const Sub& x, const Sub& y) { return x.verts.size() > y.verts.size(); });
+  std::atomic<size_t> next(0);
+  std::atomic<bool> failed(false);
+  auto worker = [&](Dissector* mine) {
+    try {
+      Dissector local_d(aptr, arow, mine ? 0 : n);
+      Dissector& d = mine ? *mine : local_d;
+      std::vector<Sub> own;
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= stack.size()) break;
+        own.clear();
+        own.push_back(std::move(stack[k]));
+        while (!own.empty()) dissect_one(d, own, perm, leaf_size);
+      }
+    } catch (...) {
+      failed = true;
+    }
+  };
+  std::vector<std::thread> pool;
+  try {
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker, static_cast<Dissector*>(nullptr));
+  } catch (...) {          // (no more threads to be had: the ones that started and this one do the work)
+  }
+  worker(&d0);
+  for (auto& th : pool) th.join();
+  if (failed) throw std::bad_alloc();
 }
 
 

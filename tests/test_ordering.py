@@ -68,3 +68,22 @@ def test_amd_on_a_star_and_a_path():
     col = np.r_[i, i[:-1]]
     perm, nfac, _ = analyse(n, row, col, np.ones(len(row)), 2, nemin=1)
     assert nfac == 2 * n - 1
+
+
+@pytest.mark.parametrize("name", ["grid2d_520", "kkt_250k"])
+def test_nested_dissection_is_the_same_on_one_and_on_several_threads(name, monkeypatch):
+    """The default ordering shares the pieces of the dissection tree out to worker threads once the top cuts have been
+    made (gsls_order.cpp: order_nested_dissection, graphs of 200 000 vertices and more).  Every piece is processed with
+    scratch arrays of the worker's own and gets what it would get alone: the permutation must not depend on the number
+    of threads or on the schedule (SSIDS' METIS call is deterministic too, ssids.f90:305-320)."""
+    prob = P.grid2d(520, 520) if name == "grid2d_520" else P.kkt_qpband(210000, 40000)
+    n, row, col, val = prob[:4]
+    ref = None
+    for threads in ("1", "2", "4", "7", "4"):
+        monkeypatch.setenv("GSLS_ND_THREADS", threads)
+        perm, nfact, nflops = analyse(n, row, col, val, 1)
+        assert np.array_equal(np.sort(perm), np.arange(1, n + 1))
+        if ref is None:
+            ref = (perm, nfact, nflops)
+        else:
+            assert np.array_equal(perm, ref[0]) and (nfact, nflops) == ref[1:], threads
