@@ -1,5 +1,7 @@
-"""Diagnostic build (-DGSLS_STAMPS, galahad_amd/libgsls_stamps.so copied over libgsls.so on the box): where the waves of
-the bottom-stage forward kernel (k_wsolve_fwd narrow) spend their time on the metric workload, summed over one launch."""
+"""Where the waves of the bottom-stage forward kernel (k_wsolve_fwd narrow) spend their time on the metric workload, summed
+over one launch.  Needs the diagnostic build: `GSLS_EXTRA=-DGSLS_STAMPS bash galahad_amd/csrc/build.sh`, keep the result as
+galahad_amd/libgsls_stamps.so, rebuild the product, and on the GPU box copy the diagnostic library over libgsls.so before
+running this (the product library does not export gsls_debug_stamps).  Result of round 2: profiles/r02/solve_experiments.txt."""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, problems as P
