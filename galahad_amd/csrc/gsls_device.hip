@@ -2943,9 +2943,113 @@ __device__ __forceinline__ void wave_fwd_load(const WTask& t, int lane, WFwdPre<
   }
 }
 
+// The NARROW kernels' form of the same load (round 3).  Measured on the bottom stage of the metric workload
+// (tools/wsolve_ubench.hip, profiles/r03/ubench_wsolve.txt): one 16-byte load instruction per column pair costs about as
+// much whether it brings 464 bytes or none (16 instructions per front: 54 us for 140 MB; 12: 48 us; the same bytes as 4
+// full-wave pieces: 39 us), and the seven small loads beside the image -- issued for all 64 lanes, 4 x 1 KB of D alone --
+// another 11 us.  Hence
+//   * the image is read as a FLAT stream, ceil(bytes / 1024) loads of 16 bytes per lane over consecutive addresses,
+//     and handed to the lanes that own the entries through LDS (the packed layout is unchanged: the writers are);
+//   * the small loads are masked to the lanes that use them (buffer descriptors sized to the front: a lane out of
+//     range costs no request), D^-1 is ONE 16-byte load per pivot, its neighbours' words come by lane shifts.
+// A 2x2 pivot never straddles two fronts, so the word of the next front's first pivot that the unmasked form read
+// for the last lane (never inf) can be any finite number: the masked load returns 0.
+constexpr int WIMG_BYTES = 6144;      // LDS staging area per wave: the largest image of a narrow front (n <= 32, m <= 40)
+constexpr int WACC_NARROW = 40;       // ... and the row length of its LDS accumulators (64 otherwise)
+constexpr int WIMG_CHUNKS = WIMG_BYTES / 1024;
+constexpr unsigned WBUF_FLAGS = 0x00020000;
+
+template <class T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(const T* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, bytes, WBUF_FLAGS);
+}
+__device__ __forceinline__ double wave_ld_f64(__amdgpu_buffer_rsrc_t rs, int off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+}
+template <int AUX = 0>
+__device__ __forceinline__ double2_t wave_ld_f64x2(__amdgpu_buffer_rsrc_t rs, int off, int soff) {
+  return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, AUX));
+}
+// Cache policy of the image loads (2 = nt).  The forward image is read once per solve and its 170 MB pass through the
+// caches right after the factorization wrote both images; as nt loads they leave the small vectors (right-hand side, D,
+// maps, contribution vectors) and the backward image where later kernels find them: bottom stage 46.7 -> 37.9 us,
+// whole sweep 187 -> 171 us (profiles/r03/solve_experiments.txt).  On the backward image it makes no difference.
+#ifndef GSLS_WS_NT_F
+#define GSLS_WS_NT_F 2
+#endif
+#ifndef GSLS_WS_NT_B
+#define GSLS_WS_NT_B 0
+#endif
+
+// issue: the flat pieces of the image and the masked small loads
+template <bool APPLY_D>
+struct WFwdFlat {
+  double2_t ch[WIMG_CHUNKS];
+  double2_t dd;
+  double rhs;
+  int gp, pr;
+};
+template <bool APPLY_D>
+__device__ __forceinline__ void wave_fwd_issue(const WTask& t, int lane, WFwdFlat<APPLY_D>& q, const double* __restrict__ Lf,
+                                               const double* __restrict__ D, const int32_t* __restrict__ gperm,
+                                               const int32_t* __restrict__ cmap, const double* __restrict__ xp) {
+  const int m = t.m, n = t.n;
+  const int npair = (n + 1) >> 1;
+  const int nbytes = 16 * (npair * (m - 1) - npair * (npair - 1));
+  const int oob = int(0x80000000);
+  const __amdgpu_buffer_rsrc_t rs = wave_rsrc(Lf + t.lfoff, nbytes);
+#pragma unroll
+  for (int c = 0; c < WIMG_CHUNKS; ++c) {
+    q.ch[c] = double2_t{0.0, 0.0};
+    if (c < 2 || c * 1024 < nbytes) q.ch[c] = wave_ld_f64x2<GSLS_WS_NT_F>(rs, lane * 16, c * 1024);   // (uniform)
+  }
+  q.rhs = wave_ld_f64(wave_rsrc(xp + t.sptr, n * 8), lane * 8);
+  q.gp = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(gperm + t.sptr, n * 4), lane * 4, 0, 0);
+  q.pr = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(cmap + t.moff, (m - n) * 4), lane >= n ? (lane - n) * 4 : oob, 0, 0);
+  q.dd = double2_t{0.0, 0.0};
+  if (APPLY_D) q.dd = wave_ld_f64x2(wave_rsrc(D + 2 * int64_t(t.sptr), n * 16), lane * 16, 0);
+}
+// arrival: through LDS to the lane = row, register = column pair form the recurrence wants
+template <bool APPLY_D>
+__device__ __forceinline__ void wave_fwd_arrive(const WTask& t, int lane, const WFwdFlat<APPLY_D>& q, WFwdPre<32>& p,
+                                                double2_t* __restrict__ im) {
+  const int m = t.m, n = t.n;
+  const int npair = (n + 1) >> 1;
+  const int nbytes = 16 * (npair * (m - 1) - npair * (npair - 1));
+#pragma unroll
+  for (int c = 0; c < WIMG_CHUNKS; ++c)
+    if (c < 2 || c * 1024 < nbytes) im[c * 64 + lane] = q.ch[c];
+  const bool row = (lane >= 1) & (lane < m);
+#pragma unroll
+  for (int j4 = 0; j4 < 16; j4 += 4) {
+    if (j4 < 8 || 2 * j4 < n) {          // (uniform; the recurrence skips the same groups of columns)
+#pragma unroll
+      for (int j = j4; j < j4 + 4; ++j) {
+        const bool ok = row & (lane >= 2 * j + 1) & (2 * j < n);
+        const double2_t v = im[ok ? j * (m - j - 2) + lane - 1 : 0];
+        p.lp[j] = ok ? v : double2_t{0.0, 0.0};
+      }
+    } else {
+#pragma unroll
+      for (int j = j4; j < j4 + 4; ++j) p.lp[j] = double2_t{0.0, 0.0};
+    }
+  }
+  const bool piv = lane < n;
+  p.rhs = q.rhs;                          // (0 from the descriptor for the lanes that are not pivots)
+  p.pslot = piv ? q.gp - t.sptr : lane;
+  p.prow = q.pr;
+  p.d0 = q.dd.x;
+  p.d1 = q.dd.y;
+  p.dn = p.dp = 0.0;
+  if (APPLY_D) {
+    p.dn = __shfl_down(q.dd.x, 1);        // D[2s + 2]: the next pivot's first word (inf: this is the first row of a 2x2)
+    p.dp = __shfl_up(q.dd.y, 1);          // D[2s - 1]: the previous pivot's second word (d21 of a 2x2 ending here)
+  }
+}
+
 // slotv != nullptr: the result goes there by pivot slot (job ALL: only the backward wave kernels read it);
 // otherwise to xp by position, like every other kernel's
-template <int NN, bool APPLY_D, bool PULLS>
+template <int NN, bool APPLY_D, bool PULLS, int AS = 64>     // AS: row length of the LDS accumulators (>= every m of the launch)
 __device__ __forceinline__ void wave_fwd_compute(const WTask& t, int lane, const WFwdPre<NN>& p, double* __restrict__ acc,
                                                  const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
                                                  double* __restrict__ xp, double* __restrict__ slotv,
@@ -2972,9 +3076,11 @@ __device__ __forceinline__ void wave_fwd_compute(const WTask& t, int lane, const
     }
   }
   if (t.flags & WT_INT) {
-    double* mine = acc + t.myslot * 64;
-    csum += mine[lane];
-    mine[lane] = 0.0;                   // ready for the next front at this depth
+    double* mine = acc + t.myslot * AS;
+    if (AS == 64 || lane < AS) {
+      csum += mine[lane];
+      mine[lane] = 0.0;                 // ready for the next front at this depth
+    }
   }
   // pivot slot r holds the analyse-time row gperm[sptr + r] - sptr (numerical pivoting inside the front)
   double x = __shfl(p.rhs + csum, p.pslot);
@@ -2994,7 +3100,7 @@ __device__ __forceinline__ void wave_fwd_compute(const WTask& t, int lane, const
     // spare slot / store to the padding behind the vector -- no branch
     const bool crow = (lane >= n) & (lane < m);
     const bool push = (t.flags & WT_PUSH) != 0;
-    double* a = acc + ((crow & push) ? t.pslot * 64 + p.prow : WSLOT * 64 + lane);
+    double* a = acc + ((crow & push) ? t.pslot * AS + p.prow : WSLOT * AS + lane);
     *a += (crow & push) ? x : 0.0;
     if (!push && crow) cvec[t.moff + lane - n] = x;
   }
@@ -3059,7 +3165,61 @@ __device__ __forceinline__ void wave_bwd_load(const WTask& t, int lane, WBwdPre<
   }
 }
 
-template <int MM, bool PULLS>
+// the NARROW backward kernel's load: flat image + masked small loads, as wave_fwd_issue / wave_fwd_arrive
+struct WBwdFlat {
+  double2_t ch[WIMG_CHUNKS];
+  double xs, z;
+  int gp, gv, pr;
+};
+__device__ __forceinline__ void wave_bwd_issue(const WTask& t, int lane, WBwdFlat& q, const double* __restrict__ Lb,
+                                               const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
+                                               const int32_t* __restrict__ cmap, const double* __restrict__ slotv,
+                                               const double* __restrict__ cvec) {
+  const int m = t.m, n = t.n;
+  const int nbytes = 16 * wb_pair_off((m + 1) >> 1, n);
+  const int oob = int(0x80000000);
+  const __amdgpu_buffer_rsrc_t rs = wave_rsrc(Lb + t.lboff, nbytes);
+#pragma unroll
+  for (int c = 0; c < WIMG_CHUNKS; ++c) {
+    q.ch[c] = double2_t{0.0, 0.0};
+    if (c < 2 || c * 1024 < nbytes) q.ch[c] = wave_ld_f64x2<GSLS_WS_NT_B>(rs, lane * 16, c * 1024);   // (uniform)
+  }
+  const int co = lane >= n ? (lane - n) : oob;
+  q.gp = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(gperm + t.sptr, n * 4), lane * 4, 0, 0);
+  q.gv = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(gvar + t.sptr, n * 4), lane * 4, 0, 0);
+  q.pr = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(cmap + t.moff, (m - n) * 4), lane >= n ? co * 4 : oob, 0, 0);
+  q.xs = wave_ld_f64(wave_rsrc(slotv + t.sptr, n * 8), lane * 8);
+  q.z = wave_ld_f64(wave_rsrc(cvec + t.moff, (m - n) * 8), lane >= n ? co * 8 : oob);
+}
+__device__ __forceinline__ void wave_bwd_arrive(const WTask& t, int lane, const WBwdFlat& q, WBwdPre<40>& p,
+                                                double2_t* __restrict__ im) {
+  const int m = t.m, n = t.n;
+  const int nbytes = 16 * wb_pair_off((m + 1) >> 1, n);
+#pragma unroll
+  for (int c = 0; c < WIMG_CHUNKS; ++c)
+    if (c < 2 || c * 1024 < nbytes) im[c * 64 + lane] = q.ch[c];
+  const bool colv = lane < n;
+#pragma unroll
+  for (int i4 = 0; i4 < 20; i4 += 4) {
+    if (i4 < 12 || 2 * i4 < m) {          // (uniform; the recurrence skips the same groups of rows)
+#pragma unroll
+      for (int i = i4; i < i4 + 4; ++i) {
+        const bool ok = colv & (lane <= 2 * i) & (2 * i < m);
+        const double2_t v = im[ok ? wb_pair_off(i, n) + lane : 0];
+        p.up[i] = ok ? v : double2_t{0.0, 0.0};
+      }
+    } else {
+#pragma unroll
+      for (int i = i4; i < i4 + 4; ++i) p.up[i] = double2_t{0.0, 0.0};
+    }
+  }
+  p.pos = q.gp;
+  p.var = q.gv;
+  p.prow = q.pr;
+  p.x = colv ? q.xs : q.z;                // (z = 0 from the descriptor for the lanes from m on)
+}
+
+template <int MM, bool PULLS, int AS = 64>
 __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const WBwdPre<MM>& p, double* __restrict__ xfull,
                                                  const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
                                                  double* __restrict__ xp, double* __restrict__ xout,
@@ -3068,7 +3228,7 @@ __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const
   double x = p.x;
   {
     const bool arow = ((t.flags & WT_PUSH) != 0) & (lane >= n) & (lane < m);
-    const double xv = xfull[arow ? t.pslot * 64 + p.prow : WSLOT * 64 + lane];
+    const double xv = xfull[arow ? t.pslot * AS + p.prow : WSLOT * AS + lane];
     x = arow ? xv : x;
   }
 #pragma unroll
@@ -3086,7 +3246,7 @@ __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const
   // pivot slot `lane` holds the analyse-time row gperm[sptr + lane] - sptr (numerical pivoting inside the front); the
   // children address the front by analyse-time rows (cmap, gather lists)
   const int arow = (lane < n) ? p.pos - t.sptr : lane;
-  if (t.flags & WT_INT) xfull[t.myslot * 64 + arow] = x;       // for the children inside the group
+  if ((t.flags & WT_INT) && (AS == 64 || lane < m)) xfull[t.myslot * AS + arow] = x;       // for the children inside the group
   if (PULLS && (t.flags & WT_PULL)) {                          // ... and for those of earlier stages
     const int lr = min(arow, m - 1);
     const int g0 = gth_ptr[t.goff + lr], g1 = (lane < m) ? gth_ptr[t.goff + lr + 1] : g0;
@@ -3113,14 +3273,15 @@ __device__ __forceinline__ WTask wave_task(const WTask* __restrict__ tasks, int 
 // NARROW: every front of the launch has at most 32 pivot columns: the loads of the group's next front are in flight
 // while the wave works on the current one (two register sets, A and B).  Otherwise fronts of 33..64 columns are
 // among them: one at a time (two 64-column register sets do not fit).
-template <bool APPLY_D, bool NARROW>
+template <bool APPLY_D, bool NARROW, bool FLAT = false>
 __global__ void __launch_bounds__(256)
 k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restrict__ tasks,
              const double* __restrict__ Lf, const double* __restrict__ D, const int32_t* __restrict__ gperm,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, double* __restrict__ slotv,
              double* __restrict__ cvec, Cols cs) {
-  __shared__ double accs[4][(WSLOT + 1) * 64];    // + a spare row for the masked lanes
+  constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
+  __shared__ double accs[4][WSLOT * AS + 64];     // + a spare row (64 wide) for the masked lanes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GSLS_COLS;
   xp += col_ * cs.sx;
@@ -3130,7 +3291,7 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
   if (gi >= ngroup) return;
   double* acc = accs[wave];
 #pragma unroll
-  for (int i = 0; i <= WSLOT; ++i) acc[i * 64 + lane] = 0.0;
+  for (int i = 0; i < WSLOT * AS + 64; i += 64) acc[i + lane] = 0.0;
   const WGroup g = groups[gi];
   const int te = g.tbeg + g.tcnt;
   if constexpr (NARROW) {
@@ -3152,13 +3313,20 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
     while (true) {
       const WTask tb = wave_task(tasks, min(ti + 1, te - 1));
       WFwdPre<32> A;
-      wave_fwd_load<32, APPLY_D>(ta, lane, A, Lf, D, gperm, cmap, xp);
+      if constexpr (FLAT) {
+        __shared__ __attribute__((aligned(16))) double2_t wimg[4][WIMG_BYTES / 16];
+        WFwdFlat<APPLY_D> Q;
+        wave_fwd_issue<APPLY_D>(ta, lane, Q, Lf, D, gperm, cmap, xp);
+        wave_fwd_arrive<APPLY_D>(ta, lane, Q, A, wimg[wave]);
+      } else {
+        wave_fwd_load<32, APPLY_D>(ta, lane, A, Lf, D, gperm, cmap, xp);
+      }
 #ifdef GSLS_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WPH(ph0);                           // image, right-hand side, D, maps: issue -> arrival
       ++nfr;
 #endif
-      wave_fwd_compute<32, APPLY_D, false>(ta, lane, A, acc, gth_ptr, gth_src, xp, slotv, cvec);
+      wave_fwd_compute<32, APPLY_D, false, AS>(ta, lane, A, acc, gth_ptr, gth_src, xp, slotv, cvec);
 #ifdef GSLS_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       WPH(ph1);                           // recurrence, LDS hand-off, stores issued (and the next task record arrived)
@@ -3192,14 +3360,15 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
 }
 
 // NARROW: every front of the launch has at most 40 rows (two register sets, as in the forward kernel)
-template <bool NARROW>
+template <bool NARROW, bool FLAT = false>
 __global__ void __launch_bounds__(256)
 k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restrict__ tasks,
              const double* __restrict__ Lb, const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ rlist, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, const double* __restrict__ slotv,
              double* __restrict__ xout, const double* __restrict__ scale, double* __restrict__ cvec, Cols cs) {
-  __shared__ double xfs[4][(WSLOT + 1) * 64];
+  constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
+  __shared__ double xfs[4][WSLOT * AS + 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GSLS_COLS;
   xp += col_ * cs.sx;
@@ -3217,8 +3386,15 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
     while (true) {
       const WTask tb = wave_task(tasks, max(ti - 1, g.tbeg));
       WBwdPre<40> A;
-      wave_bwd_load<40, true>(ta, lane, A, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
-      wave_bwd_compute<40, false>(ta, lane, A, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+      if constexpr (FLAT) {
+        __shared__ __attribute__((aligned(16))) double2_t wimg[4][WIMG_BYTES / 16];
+        WBwdFlat Q;
+        wave_bwd_issue(ta, lane, Q, Lb, gperm, gvar, cmap, slotv, cvec);
+        wave_bwd_arrive(ta, lane, Q, A, wimg[wave]);
+      } else {
+        wave_bwd_load<40, true>(ta, lane, A, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+      }
+      wave_bwd_compute<40, false, AS>(ta, lane, A, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
       if (--ti < g.tbeg) break;
       ta = tb;
     }
@@ -3234,6 +3410,97 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
         wave_bwd_load<64, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
         wave_bwd_compute<64, true>(t, lane, P, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
       }
+    }
+  }
+}
+
+// The TOP of the tier in one launch (round 3).  The last stages of a tree hold a handful of fronts each (metric
+// workload: 4, 1, 1), and a launch per stage and direction costs 4 - 7 us of which the arithmetic is a fraction: a
+// chain of dependent round trips to memory (group record -> task record -> gather lists -> contribution vectors) plus
+// the launch itself.  Here ONE workgroup of eight waves walks those stages bottom-up, applies D^-1 (the forward
+// step does that) and walks them top-down again, with a workgroup barrier where a launch boundary was; the eight
+// waves of a stage take its groups in turn.  Vectors still travel through cvec / xp / slotv in memory -- waves of one
+// workgroup share the CU's vector cache, so the barrier's workgroup-scope fence is all the coherence this needs (no
+// L2 write-back: the cost that ruled out chaining workgroups on different XCDs).  The first thing the kernel does is
+// to touch every task record, image and gather list of its stages, so that the dependent accesses of the sweep find
+// them in this XCD's L2.
+constexpr int WTAIL_STAGES = 8, WTAIL_WAVES = 8;
+struct WTail {
+  int nst;
+  int gbeg[WTAIL_STAGES], gcnt[WTAIL_STAGES];   // group ranges of the tail's stages, bottom-up
+  int tbeg, tcnt;                               // their tasks (one range: launch order)
+  int64_t lf0, lf1, lb0, lb1;                   // element ranges of their images
+  int64_t gp0, gp1, gs0, gs1;                   // ... of their gather pointers / sources
+};
+template <bool APPLY_D>
+__global__ void __launch_bounds__(64 * WTAIL_WAVES)
+k_wsolve_tail(WTail tl, const WGroup* __restrict__ groups, const WTask* __restrict__ tasks,
+              const double* __restrict__ Lf, const double* __restrict__ Lb, const double* __restrict__ D,
+              const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar, const int32_t* __restrict__ cmap,
+              const int32_t* __restrict__ rlist, const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
+              double* __restrict__ xp, double* __restrict__ slotv, double* __restrict__ xout,
+              const double* __restrict__ scale, double* __restrict__ cvec, Cols cs, int do_fwd, int do_bwd,
+              double* __restrict__ sink) {
+  __shared__ double accs[WTAIL_WAVES][(WSLOT + 1) * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col_ = blockIdx.x;
+  xp += col_ * cs.sx;
+  cvec += col_ * cs.scv;
+  if (slotv) slotv += col_ * cs.sxs;
+  if (xout) xout += col_ * cs.sio;
+  double* acc = accs[wave];
+#pragma unroll
+  for (int i = 0; i <= WSLOT; ++i) acc[i * 64 + lane] = 0.0;
+  {
+    // warm this XCD's L2: one 64-byte line per lane and round
+    double warm = 0.0;
+    const int tid = threadIdx.x, nt = 64 * WTAIL_WAVES;
+    const double* tk = reinterpret_cast<const double*>(tasks + tl.tbeg);
+    for (int64_t i = int64_t(tid) * 8; i < int64_t(tl.tcnt) * 8; i += int64_t(nt) * 8) warm += tk[i];
+    if (do_fwd) for (int64_t i = tl.lf0 + int64_t(tid) * 8; i < tl.lf1; i += int64_t(nt) * 8) warm += Lf[i];
+    if (do_bwd) for (int64_t i = tl.lb0 + int64_t(tid) * 8; i < tl.lb1; i += int64_t(nt) * 8) warm += Lb[i];
+    for (int64_t i = tl.gp0 + int64_t(tid) * 16; i < tl.gp1; i += int64_t(nt) * 16) warm += double(gth_ptr[i]);
+    for (int64_t i = tl.gs0 + int64_t(tid) * 8; i < tl.gs1; i += int64_t(nt) * 8) warm += double(gth_src[i]);
+    if (warm == 1.2345e-300) sink[0] = warm;      // (never: keeps the loads)
+  }
+  if (do_fwd)
+    for (int sg = 0; sg < tl.nst; ++sg) {
+      for (int gi = wave; gi < tl.gcnt[sg]; gi += WTAIL_WAVES) {
+        const WGroup g = groups[__builtin_amdgcn_readfirstlane(tl.gbeg[sg] + gi)];
+        for (int ti = g.tbeg; ti < g.tbeg + g.tcnt; ++ti) {
+          const WTask t = wave_task(tasks, ti);
+          if (t.n <= 32) {
+            WFwdPre<32> P;
+            wave_fwd_load<32, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
+            wave_fwd_compute<32, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+          } else {
+            WFwdPre<64> P;
+            wave_fwd_load<64, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
+            wave_fwd_compute<64, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (do_bwd) {
+    const bool wv = xout != nullptr;
+    for (int sg = tl.nst - 1; sg >= 0; --sg) {
+      for (int gi = wave; gi < tl.gcnt[sg]; gi += WTAIL_WAVES) {
+        const WGroup g = groups[__builtin_amdgcn_readfirstlane(tl.gbeg[sg] + gi)];
+        for (int ti = g.tbeg + g.tcnt - 1; ti >= g.tbeg; --ti) {
+          const WTask t = wave_task(tasks, ti);
+          if (t.m <= 32) {
+            WBwdPre<32> P;
+            wave_bwd_load<32, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+            wave_bwd_compute<32, true>(t, lane, P, acc, gth_ptr, gth_src, xp, xout, scale, cvec);
+          } else {
+            WBwdPre<64> P;
+            wave_bwd_load<64, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+            wave_bwd_compute<64, true>(t, lane, P, acc, gth_ptr, gth_src, xp, xout, scale, cvec);
+          }
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -4094,6 +4361,24 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         tk.lfoff = nlf[tk.node];
         tk.lboff = nlb[tk.node];
       }
+      // the tail: the longest run of last stages with at most WTAIL_WAVES groups each (never stage 0)
+      F.wtail_k0 = -1;
+      if (!getenv("GSLS_NO_WTAIL")) {
+        int k0 = nstage;
+        while (k0 - 1 >= 1 && F.wstage_cnt[k0 - 1] <= WTAIL_WAVES && nstage - (k0 - 1) <= WTAIL_STAGES) --k0;
+        if (nstage - k0 >= 2) {               // (a single stage is a single launch either way)
+          F.wtail_k0 = k0;
+          F.wtail_tbeg = wg[F.wstage_begin[k0]].tbeg;
+          F.wtail_tcnt = nT - F.wtail_tbeg;
+          F.wtail_lf0 = wt[F.wtail_tbeg].lfoff;
+          F.wtail_lb0 = wt[F.wtail_tbeg].lboff;
+          F.wtail_gp0 = F.wtail_gp1 = int64_t(gptr.size()) - 1;
+          for (int64_t ti = F.wtail_tbeg; ti < nT; ++ti)
+            if (wt[ti].flags & WT_PULL) F.wtail_gp0 = std::min<int64_t>(F.wtail_gp0, wt[ti].goff);
+          F.wtail_gs0 = gptr[F.wtail_gp0];
+          F.wtail_gs1 = int64_t(gsrc.size());
+        }
+      }
       std::vector<int32_t> nont;
       for (int s = 0; s < nn; ++s)
         if (!waveT[s]) nont.push_back(s);
@@ -4756,18 +5041,22 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   double* slotv = (wave && do_fwd && do_bwd) ? w_xs : nullptr;
   // (experiment knob: unused dynamic LDS per workgroup of the narrow wave kernels = fewer waves per CU)
   static const size_t ws_pad = getenv("GSLS_WS_LDSPAD") ? size_t(atoi(getenv("GSLS_WS_LDSPAD"))) : 0;
+  static const bool ws_flat = !(getenv("GSLS_WS_FLAT") && atoi(getenv("GSLS_WS_FLAT")) == 0);   // (A/B knob)
   auto wave_fwd = [&](int g0, int cnt, bool narrow) {
     if (cnt <= 0) return;
-#define GSLS_WFWD(D_, N_)                                                                                          \
-  hipLaunchKernelGGL((k_wsolve_fwd<D_, N_>), dim3(((cnt + 3) / 4) * R), dim3(256), (N_) ? ws_pad : 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
+#define GSLS_WFWD(D_, N_, F_)                                                                                      \
+  hipLaunchKernelGGL((k_wsolve_fwd<D_, N_, F_>), dim3(((cnt + 3) / 4) * R), dim3(256), (N_) ? ws_pad : 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
                      F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cs)
-    if (fuse_d) { if (narrow) GSLS_WFWD(true, true); else GSLS_WFWD(true, false); }
-    else { if (narrow) GSLS_WFWD(false, true); else GSLS_WFWD(false, false); }
+    if (fuse_d) { if (narrow) { if (ws_flat) GSLS_WFWD(true, true, true); else GSLS_WFWD(true, true, false); } else GSLS_WFWD(true, false, false); }
+    else { if (narrow) { if (ws_flat) GSLS_WFWD(false, true, true); else GSLS_WFWD(false, true, false); } else GSLS_WFWD(false, false, false); }
 #undef GSLS_WFWD
   };
   auto wave_bwd = [&](int g0, int cnt, bool narrow) {
     if (cnt <= 0) return;
-    if (narrow)
+    if (narrow && ws_flat)
+      hipLaunchKernelGGL((k_wsolve_bwd<true, true>), dim3(((cnt + 3) / 4) * R), dim3(256), ws_pad, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs);
+    else if (narrow)
       hipLaunchKernelGGL(k_wsolve_bwd<true>, dim3(((cnt + 3) / 4) * R), dim3(256), ws_pad, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
                          F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs);
     else
@@ -4776,12 +5065,38 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   };
   if (ev) HIPCHK(hipEventRecord(ev[0], st));
   const bool ahead = slotv != nullptr && scale == nullptr;  // the look-ahead kernels: job ALL, no user scaling
-  if (do_fwd && wave)
-    for (size_t k = 0; k < F.wstage_cnt.size(); ++k) {      // stages of small subtrees, bottom-up
+  // the last stages in one launch (k_wsolve_tail); with nothing above the tier, both directions in the same launch
+  const int nstage = int(F.wstage_cnt.size());
+  const int ktail = (wave && F.wtail_k0 >= 1) ? F.wtail_k0 : nstage;
+  const bool tail_both = ktail < nstage && do_fwd && do_bwd && F.wnont_cnt == 0;
+  auto wave_tail = [&](int df, int db) {
+    WTail tl;
+    tl.nst = nstage - ktail;
+    for (int k = 0; k < WTAIL_STAGES; ++k) {
+      tl.gbeg[k] = k < tl.nst ? F.wstage_begin[ktail + k] : 0;
+      tl.gcnt[k] = k < tl.nst ? F.wstage_cnt[ktail + k] : 0;
+    }
+    tl.tbeg = F.wtail_tbeg;
+    tl.tcnt = F.wtail_tcnt;
+    tl.lf0 = F.wtail_lf0; tl.lf1 = F.Lf_elems;
+    tl.lb0 = F.wtail_lb0; tl.lb1 = F.Lb_elems;
+    tl.gp0 = F.wtail_gp0; tl.gp1 = F.wtail_gp1;
+    tl.gs0 = F.wtail_gs0; tl.gs1 = F.wtail_gs1;
+    if (fuse_d && df)
+      hipLaunchKernelGGL(k_wsolve_tail<true>, dim3(R), dim3(64 * WTAIL_WAVES), 0, st, tl, wgr, wtk, F.Lf, F.Lb, F.D, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, df, db, F.D);
+    else
+      hipLaunchKernelGGL(k_wsolve_tail<false>, dim3(R), dim3(64 * WTAIL_WAVES), 0, st, tl, wgr, wtk, F.Lf, F.Lb, F.D, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, df, db, F.D);
+  };
+  if (do_fwd && wave) {
+    for (int k = 0; k < ktail; ++k) {                       // stages of small subtrees, bottom-up
       const int nar = ahead ? F.wstage_narrow[k] : 0;
       wave_fwd(F.wstage_begin[k], nar, true);
       wave_fwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false);
     }
+    if (ktail < nstage) wave_tail(1, tail_both ? 1 : 0);
+  }
   if (do_fwd)
     for (int l = 0; l < S.nlevels; ++l) {
       const LevelPlan& lp = plan[l];
@@ -4869,8 +5184,9 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
         }
       }
     }
+  if (do_bwd && wave && ktail < nstage && !tail_both) wave_tail(0, 1);
   if (do_bwd && wave)
-    for (int k = int(F.wstage_cnt.size()) - 1; k >= 0; --k) {
+    for (int k = ktail - 1; k >= 0; --k) {
       const int nar = ahead ? F.wstage_narrow[k] : 0;
       wave_bwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false);
       wave_bwd(F.wstage_begin[k], nar, true);

@@ -147,6 +147,10 @@ struct DeviceFactor {
   int wtask_cnt = 0;
   std::vector<int> wstage_begin, wstage_cnt, wstage_narrow;   // per stage: group range, and how many of its first
                                                               // groups hold fronts of at most 32 columns only
+  // the last stages, a handful of fronts each, run in one launch (k_wsolve_tail): first such stage (-1: none), its
+  // tasks and the element ranges of their images / gather lists
+  int wtail_k0 = -1, wtail_tbeg = 0, wtail_tcnt = 0;
+  int64_t wtail_lf0 = 0, wtail_lb0 = 0, wtail_gp0 = 0, wtail_gp1 = 0, wtail_gs0 = 0, wtail_gs1 = 0;
   int32_t* wgth_ptr = nullptr;    // gather lists of the covered fronts (rows -> children's contribution entries)
   int64_t* wgth_src = nullptr;
   int32_t* wnont = nullptr;       // fronts the tier does not cover (for the D solve)
