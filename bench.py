@@ -112,14 +112,32 @@ def cpu_baseline(prob, posdef, perm, nemin):
     if best is None:
         return None
     t, threads, r = best
-    return {"value": r["flops_elimination"] / t / 1e9, "unit": "GF/s", "cores": threads,
+    # second baseline: the same reference build with the optimised OpenBLAS that ships inside
+    # scipy behind SSIDS' BLAS / LAPACK calls (oracle/blas_shim.c, LD_PRELOAD), at the best thread count found above
+    ob = None
+    if refio.openblas_available():
+        try:
+            r2 = refio.run(n, row, col, val, rhs, perm=perm, pivot_control=2 if posdef else 1, nemin=nemin,
+                           repeat=3, threads=threads, timeout=1500, blas="openblas")
+            if r2["status_factorize"] == 0 and r2["status_solve"] == 0:
+                t2 = r2["t_factorize_median"] + r2["t_solve_median"]
+                ob = {"value": r2["flops_elimination"] / t2 / 1e9, "factorize_s": r2["t_factorize_median"],
+                      "solve_s": r2["t_solve_median"], "max_err": float(np.abs(r2["x"] - xs).max())}
+        except Exception as e:
+            ob = {"error": repr(e)[:200]}
+    vendored = r["flops_elimination"] / t / 1e9
+    value = max(vendored, ob["value"]) if ob and "value" in ob else vendored
+    return {"value": value, "unit": "GF/s", "cores": threads,
             "kind": "reference",
             "sample": "full workload, same PERM and nemin as the GPU run, median of 3 SLS_factorize+SLS_solve "
-                      "(ssids, vendored reference BLAS, OMP_NUM_THREADS=%d of %d usable cores): factorize %.3fs "
-                      "solve %.3fs analyse %.2fs; GF/s by OpenMP thread count (one socket and beyond): %s; no optimized "
-                      "BLAS exists on the box to link a second baseline against"
-                      % (threads, host_cores(), r["t_factorize_median"], r["t_solve_median"], r["t_analyse"],
+                      "(ssids, OMP_NUM_THREADS=%d of %d usable cores); `value` is the better of two builds of the "
+                      "reference: vendored reference BLAS %.2f GF/s (factorize %.3fs solve %.3fs analyse %.2fs), "
+                      "OpenBLAS from scipy.libs behind SSIDS' BLAS/LAPACK calls %s; vendored-BLAS GF/s by OpenMP "
+                      "thread count (one socket and beyond): %s"
+                      % (threads, host_cores(), vendored, r["t_factorize_median"], r["t_solve_median"], r["t_analyse"],
+                         ("%.2f GF/s" % ob["value"]) if ob and "value" in ob else "unavailable",
                          ", ".join("%d: %.2f" % tv for tv in sweep)),
+            "vendored_blas": vendored, "openblas": ob,
             "thread_sweep": sweep,
             "flops_elimination": r["flops_elimination"], "entries_in_factors": r["entries_in_factors"],
             "delayed_pivots": r["delayed"], "negative_eigenvalues": r["negative_eigenvalues"],
@@ -138,7 +156,8 @@ def facade_timings(prob, a, nemin):
     try:
         r = refio.run(n, row, col, val, rhs, solver="gsls", pivot_control=1, nemin=nemin, repeat=7, max_refine=0)
         r1 = refio.run(n, row, col, val, rhs, solver="gsls", pivot_control=1, nemin=nemin, repeat=7, max_refine=1)
-        out["sls"] = {"factorize_ms": r["t_factorize_median"] * 1e3, "solve_ms": r["t_solve_median"] * 1e3,
+        out["sls"] = {"gflops": r["flops_elimination"] / (r["t_factorize_median"] + r["t_solve_median"]) / 1e9,
+                      "factorize_ms": r["t_factorize_median"] * 1e3, "solve_ms": r["t_solve_median"] * 1e3,
                       "solve_with_one_refinement_ms": r1["t_solve_median"] * 1e3,
                       "status": [r["status_analyse"], r["status_factorize"], r["status_solve"]],
                       "max_err": float(np.abs(r["x"] - xs).max())}
@@ -149,7 +168,8 @@ def facade_timings(prob, a, nemin):
                  np.concatenate([np.arange(a.m), a.m + np.arange(a.m)]) + 1, np.ones(2 * a.m))
             Cm = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
             rs = refio.run_sbls(a.n, a.m, H, A, Cm, rhs, solver="gsls", factorization=2, repeat=7, itref_max=1)
-            out["sbls"] = {"form_and_factorize_ms": rs["t_factorize_median"] * 1e3, "solve_ms": rs["t_solve_median"] * 1e3,
+            out["sbls"] = {"gflops": r["flops_elimination"] / (rs["t_factorize_median"] + rs["t_solve_median"]) / 1e9,
+                           "form_and_factorize_ms": rs["t_factorize_median"] * 1e3, "solve_ms": rs["t_solve_median"] * 1e3,
                            "status": [rs["status_factorize"], rs["status_solve"]],
                            "max_err": float(np.abs(rs["sol"] - xs).max()),
                            "note": "SBLS_solve_explicit (src/sbls/sbls.f90:5073-5388) with its refinement loop handed to the backend "
@@ -159,11 +179,50 @@ def facade_timings(prob, a, nemin):
     return out
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself, as CHILD processes with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, and never touches the GPU or torch (no re-exec of a process that
+    has initialised HIP).  Rank 0 prints the JSON line on the inherited stdout; a failing rank ends the run non-zero."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+                for q in live:          # the others would wait for it in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if a.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs and what n_gpus reports"
+              % (a.gpus, world), file=sys.stderr)
+    if os.environ.get("GSLS_BENCH_SPAWN_ONLY"):     # (tests/test_dist.py: the rank plumbing without a GPU)
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world,
+                          "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), flush=True)
+        return
     import torch
     import torch.distributed as dist
     from galahad_amd import dist as gdist
@@ -237,8 +296,15 @@ def main():
         f = lib.gsls_factor_dev(s.handle, 1 if posdef else 0, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts),
                                 C.byref(ginf))
         assert f >= 0, f
-        d_x.copy_(d_rhs)
-        torch.cuda.current_stream().synchronize()
+        # the right-hand side is copied on the library's own stream (the handle's, behind the factorization): no host
+        # synchronisation between the factorization and the solve
+        hs = lib.gsls_get_stream(s.handle)
+        if hs:
+            with torch.cuda.stream(torch.cuda.ExternalStream(hs)):
+                d_x.copy_(d_rhs, non_blocking=True)
+        else:
+            d_x.copy_(d_rhs)
+            torch.cuda.current_stream().synchronize()
         f = lib.gsls_solve_dev(s.handle, 0, 1, C.c_void_p(d_x.data_ptr()), n, C.byref(s.opts), C.byref(ginf))
         assert f >= 0, f
 
@@ -318,9 +384,11 @@ def main():
         # HBM bytes of one solve sweep from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
         # collected separately with rocprofv3 --pmc and committed; only valid for the profiled config
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic_%s.json" % a.workload)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_%s.json" % a.workload)))
+        pmc = cands[-1] if cands else ""      # the newest round's PMC pass (tools/measure_round.sh)
         default_shape = (kkt and a.n == 1000000 and a.m == 200000) or (not kkt and a.n == 100000 and a.semibw == 127)
-        if os.path.exists(pmc) and default_shape and a.ordering == "free" and a.nemin == 0:
+        if pmc and os.path.exists(pmc) and default_shape and a.ordering == "free" and a.nemin == 0:
             with open(pmc) as f:
                 traffic = json.load(f)["solve_sweep"]["hbm_bytes_corrected"]
         out = {

@@ -92,8 +92,17 @@ def read_result(path, n, nrhs, dump_struct):
     return res
 
 
-def run(n, row, col, val, rhs, *, threads=None, timeout=3600, **kw):
-    """Run the reference on one problem; returns the dict of read_result()."""
+BLAS_SHIM = os.path.join(HERE, "_ref", "libblas_shim.so")
+
+
+def openblas_available():
+    return os.path.exists(BLAS_SHIM)
+
+
+def run(n, row, col, val, rhs, *, threads=None, timeout=3600, blas="vendored", **kw):
+    """Run the reference on one problem; returns the dict of read_result().
+    blas = "openblas": SSIDS' BLAS / LAPACK calls go to the OpenBLAS inside scipy (oracle/blas_shim.c, preloaded;
+    one OpenBLAS thread per caller: SSIDS parallelises over OpenMP tasks itself)."""
     if not available():
         raise RuntimeError("oracle/_ref/ref_driver not built (run oracle/build_ref.sh)")
     rhs = np.asarray(rhs, dtype=np.float64)
@@ -106,6 +115,11 @@ def run(n, row, col, val, rhs, *, threads=None, timeout=3600, **kw):
         env.setdefault("OMP_PROC_BIND", "true")
         if threads is not None:
             env["OMP_NUM_THREADS"] = str(threads)
+        if blas == "openblas":
+            if not openblas_available():
+                raise RuntimeError("oracle/_ref/libblas_shim.so not built")
+            env["LD_PRELOAD"] = BLAS_SHIM + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
+            env["OPENBLAS_NUM_THREADS"] = "1"
         # n >~ 1e6 needs an unlimited stack for SLS's automatic arrays (sls.f90:8436)
         exe = DROPIN if kw.get("solver") == "gsls" else DRIVER
         cmd = "ulimit -s unlimited 2>/dev/null; exec '%s' '%s' '%s'" % (exe, pin, pout)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): tools/measure_round.sh r02
+# usage (on the GPU box, via gpurun): tools/measure_round.sh r03
 # everything the round's measurement section cites, into gpurun_out/<round>/ (copied to profiles/<round>/ afterwards):
 #   kernel-trace stats + last-step breakdown (kkt, band), FETCH_SIZE / WRITE_SIZE passes (kkt, band), the
 #   MFMA / SQ counter passes, the FETCH_SIZE calibration, the bench lines themselves
-RND=${1:-r02}
+RND=${1:-r03}
 R=$PWD
 O=$R/gpurun_out/$RND
 mkdir -p $O
@@ -17,7 +17,7 @@ for WL in kkt band; do
   done
   (cd $R && python3 tools/pmc_traffic.py $O/pmc_${WL}_FETCH_SIZE $O/pmc_${WL}_WRITE_SIZE "$WL" > $O/pmc_traffic_$WL.json)
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $O/pmc_${WL}_SQ -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-facade > $O/pmc_${WL}_SQ.log 2>&1
-  (cd $R && python3 tools/pmc_sum.py $O/pmc_${WL}_SQ > $O/pmc_sq_$WL.txt)
+  (cd $R && python3 tools/pmc_sum.py $O/pmc_${WL}_SQ > $O/pmc_sq_$WL.txt && python3 tools/mfma_util.py $O/pmc_sq_$WL.txt > $O/mfma_util_$WL.txt)
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${WL}_GRBM -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-facade > $O/pmc_${WL}_GRBM.log 2>&1
   (cd $R && python3 tools/pmc_sum.py $O/pmc_${WL}_GRBM > $O/pmc_grbm_$WL.txt)
 done
