@@ -76,6 +76,9 @@ SIGNATURES = {
     "gsls_comm_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
     "gsls_comm_collect_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
     "gsls_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gsls_comm_factor": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.POINTER(Options), C.POINTER(Inform)]),
+    "gsls_comm_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Inform)]),
+    "gsls_comm_init_env": (C.c_int, [C.c_void_p, C.POINTER(Options)]),
     "gsls_get_order": (C.c_int, [C.c_void_p, p_i32]),
     "gsls_get_scaling": (C.c_int, [C.c_void_p, p_f64]),
     "gsls_shard_fast": (C.c_int, [C.c_void_p, i32]),

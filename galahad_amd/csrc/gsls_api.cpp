@@ -6,6 +6,7 @@
 // There is deliberately no CPU numeric path: without a HIP device factor/solve fail with -51.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -15,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "gsls_device.hpp"
@@ -59,6 +61,8 @@ struct Handle {
   int comm_ranks = 0, comm_rank = 0;
   double* cx_factor = nullptr;
   double* cx_solve = nullptr;
+  double* cx_hostx = nullptr;     // gsls_comm_solve: the host caller's vector on the device
+  int cx_hostx_cap = 0;
   int32_t* cx_fail = nullptr;     // nranks x (1 + GSLS_FAILCAP): every rank's failed pivots (all-gather)
   int64_t cx_factor_elems = 0, cx_solve_elems = 0, cx_cut_elems = 0;         // the device-side front flags no longer match tppvar / the current tree
   int nemin = 32;
@@ -349,6 +353,11 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
   h->analysed = true;
   inform->time_analyse = now() - t0;
   h->last = *inform;
+  if (h->comm) (void)gsls_comm_destroy(h);     // a new pattern: the old sharding is gone
+  {
+    const int cf = gsls_comm_init_env(h, options);   // GSLS_COMM_RANKS / _RANK / _ID_FILE: several GPUs, unchanged caller
+    if (cf < 0) return inform->flag = cf;
+  }
   return flag;
 }
 
@@ -558,13 +567,21 @@ static int reanalyse(Handle* h, std::vector<int32_t>& order, gsls_inform* inform
   return GSLS_SUCCESS;
 }
 
+// scale_on_host: where the caller's scale vector lives when that differs from the values (gsls_factor_coo: the values
+// were mapped on the device, the scale vector is still the caller's host array); -1 = where `on_device` says
 static int factor_common(Handle* h, int posdef, const double* val, const double* scale, bool on_device,
-                         const gsls_options* options, gsls_inform* inform) {
+                         const gsls_options* options, gsls_inform* inform, int scale_on_host = -1) {
   gsls_inform local;
   if (!inform) inform = &local;
   if (!h || !h->analysed) {
     std::memset(inform, 0, sizeof(*inform));
     return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  if (h->comm && h->comm_ranks > 1) {
+    // the handle is one rank of a sharded system (gsls_comm_init / gsls_comm_init_env): the whole call is collective
+    if (scale) { *inform = h->last; return inform->flag = GSLS_ERROR_UNIMPLEMENTED; }   // (a user scale vector is not sharded)
+    return on_device ? gsls_comm_factor_dev(h, posdef, val, options, inform)
+                     : gsls_comm_factor(h, posdef, val, options, inform);
   }
   *inform = h->last;
   inform->flag = GSLS_SUCCESS;
@@ -647,7 +664,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
         hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&F.scale), h->S.n * sizeof(double));
         if (e2 != hipSuccess) return e2;
       }
-      const bool host_vec = !on_device || !own_scale.empty();
+      const bool host_vec = !on_device || !own_scale.empty() || scale_on_host == 1;
       hipError_t e2 = hipMemcpyAsync(F.scale, scale, h->S.n * sizeof(double),
                                      host_vec ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream);
       if (e2 != hipSuccess) return e2;
@@ -970,17 +987,10 @@ static int factor_coo_common(Handle* h, int posdef, const double* val, const dou
     *inform = h->last;
     return fail_hip(h, inform, e);
   }
-  const double* d_scale = scale;
-  if (scale && !on_device) {      // the scale vector follows the values onto the device
-    if (!h->F.scale) {
-      e = hipMalloc(reinterpret_cast<void**>(&h->F.scale), h->S.n * sizeof(double));
-      if (e != hipSuccess) return fail_hip(h, inform, e);
-    }
-    e = hipMemcpyAsync(h->F.scale, scale, h->S.n * sizeof(double), hipMemcpyHostToDevice, h->stream);
-    if (e != hipSuccess) return fail_hip(h, inform, e);
-    d_scale = h->F.scale;
-  }
-  return factor_common(h, posdef, h->F.valcsc, d_scale, true, options, inform);
+  // The caller's scale vector is handed on where it lies: factor_common stages it into F.scale itself, and does so
+  // again after every re-analysis (dev_upload_symbolic frees and rebuilds the device arrays, F.scale included -- an
+  // upload made here would be read back from freed memory by the first factorization of every pattern).
+  return factor_common(h, posdef, h->F.valcsc, scale, true, options, inform, (scale && !on_device) ? 1 : -1);
 }
 
 int gsls_factor_coo(void* handle, int32_t posdef, const double* val, const double* scale,
@@ -1124,6 +1134,17 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
     return inform->flag = GSLS_ERROR_JOB_OOR;  // ssids.f90:1205-1210
   if (nrhs < 1 || ldx < S.n || (!x && S.n > 0)) return inform->flag = GSLS_ERROR_X_SIZE;
   if (S.n == 0) return GSLS_SUCCESS;
+  if (h->comm && h->comm_ranks > 1) {
+    // one rank of a sharded system: full solves only, column by column, the whole solution on every rank
+    if (job != GSLS_SOLVE_JOB_ALL) return inform->flag = GSLS_ERROR_JOB_OOR;
+    for (int c = 0; c < nrhs; ++c) {
+      double* xc = x + int64_t(c) * ldx;
+      int f = on_device ? gsls_comm_solve_dev(h, xc, inform) : gsls_comm_solve(h, xc, inform);
+      if (f >= 0 && on_device) f = gsls_comm_collect_dev(h, xc, inform);
+      if (f < 0) return f;
+    }
+    return inform->flag;
+  }
   const double t0 = now();
   DeviceGuard g(h->device);
   DeviceFactor& F = h->F;
@@ -1406,9 +1427,11 @@ int gsls_comm_destroy(void* handle) {
   DeviceGuard g(h->device);
   if (h->comm) (void)ncclCommDestroy(h->comm);
   h->comm = nullptr;
-  for (void* p : {static_cast<void*>(h->cx_factor), static_cast<void*>(h->cx_solve), static_cast<void*>(h->cx_fail)})
+  for (void* p : {static_cast<void*>(h->cx_factor), static_cast<void*>(h->cx_solve), static_cast<void*>(h->cx_fail),
+                  static_cast<void*>(h->cx_hostx)})
     if (p) (void)hipFree(p);
-  h->cx_factor = h->cx_solve = nullptr;
+  h->cx_factor = h->cx_solve = h->cx_hostx = nullptr;
+  h->cx_hostx_cap = 0;
   h->cx_fail = nullptr;
   h->cx_factor_elems = h->cx_solve_elems = 0;
   return GSLS_SUCCESS;
@@ -1583,6 +1606,111 @@ int gsls_comm_collect_dev(void* handle, double* d_x, gsls_inform* inform) {
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   return inform->flag;
+}
+
+// ---- the same with HOST arrays: what the Fortran binding (GSLS_comm_factor / GSLS_comm_solve) and, through
+// gsls_comm_init_env, every SLS caller uses.  val: the sorted lower-by-columns values of gsls_factor; x: b on entry,
+// the WHOLE solution on exit on every rank (one extra all-reduce: a host caller wants the vector, not a shard of it).
+int gsls_comm_factor(void* handle, int32_t posdef, const double* val, const gsls_options* options, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->comm || h->S.nranks < 2) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  if (h->S.n == 0) return gsls_comm_factor_dev(handle, posdef, nullptr, options, inform);
+  if (!val) { *inform = h->last; return inform->flag = GSLS_ERROR_VAL; }
+  DeviceGuard g(h->device);
+  DeviceFactor& F = h->F;
+  const int64_t nz = h->ptr[h->S.n] - 1;
+  if (F.val_cap < nz) {
+    if (F.val) (void)hipFree(F.val);
+    F.val = nullptr;
+    F.val_cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&F.val), std::max<int64_t>(nz, 1) * sizeof(double));
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    F.val_cap = nz;
+  }
+  hipError_t e = hipMemcpyAsync(F.val, val, nz * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  return gsls_comm_factor_dev(handle, posdef, F.val, options, inform);
+}
+
+int gsls_comm_solve(void* handle, double* x, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || !h->factored || !h->comm || h->S.nranks < 2) {
+    std::memset(inform, 0, sizeof(*inform));
+    return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  }
+  if (h->S.n == 0) { *inform = h->last; return inform->flag = GSLS_SUCCESS; }
+  if (!x) { *inform = h->last; return inform->flag = GSLS_ERROR_X_SIZE; }
+  DeviceGuard g(h->device);
+  const size_t bytes = size_t(h->S.n) * sizeof(double);
+  if (h->cx_hostx_cap < h->S.n) {
+    if (h->cx_hostx) (void)hipFree(h->cx_hostx);
+    h->cx_hostx = nullptr;
+    h->cx_hostx_cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->cx_hostx), bytes);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    h->cx_hostx_cap = h->S.n;
+  }
+  hipError_t e = hipMemcpyAsync(h->cx_hostx, x, bytes, hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  int f = gsls_comm_solve_dev(handle, h->cx_hostx, inform);
+  if (f < 0) return f;
+  const int f2 = gsls_comm_collect_dev(handle, h->cx_hostx, inform);
+  if (f2 < 0) return f2;
+  e = hipMemcpy(x, h->cx_hostx, bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail_hip(h, inform, e);
+  return inform->flag = f;
+}
+
+// One sparse system over several GPUs WITHOUT any change to the caller: N copies of the same host program (one per
+// GPU, any launcher) run with
+//     GSLS_COMM_RANKS = N     GSLS_COMM_RANK = 0 .. N-1     GSLS_COMM_ID_FILE = a path all of them can reach
+// and every handle joins the communicator after its analyse (rank 0 publishes the 128-byte id through the file);
+// from then on gsls_factor / gsls_factor_coo / gsls_solve (one right-hand side, job 0) on that handle are the
+// sharded calls above -- the reference drives its devices from one ssids_factor call the same way
+// (src/ssids/fkeep.F90:99-174).  Returns 0 when the variables are not set (nothing happens), 1 when joined.
+int gsls_comm_init_env(void* handle, const gsls_options* options) {
+  const char* er = getenv("GSLS_COMM_RANKS");
+  const char* ek = getenv("GSLS_COMM_RANK");
+  const char* ef = getenv("GSLS_COMM_ID_FILE");
+  if (!er || !ek || !ef) return 0;
+  const int nranks = atoi(er), rank = atoi(ek);
+  if (nranks < 2) return 0;
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed || rank < 0 || rank >= nranks || !*ef) return GSLS_ERROR_CALL_SEQUENCE;
+  // a handle analysed again (new pattern) joins again under a fresh id: the file name carries a per-handle counter
+  static int generation = 0;
+  const std::string path = std::string(ef) + "." + std::to_string(generation++);
+  char id[128];
+  if (rank == 0) {
+    const int f = gsls_comm_unique_id(id);
+    if (f < 0) return f;
+    const std::string tmp = path + ".tmp";
+    FILE* fp = fopen(tmp.c_str(), "wb");
+    if (!fp) return GSLS_ERROR_CALL_SEQUENCE;
+    const size_t w = fwrite(id, 1, sizeof(id), fp);
+    fclose(fp);
+    if (w != sizeof(id) || rename(tmp.c_str(), path.c_str()) != 0) return GSLS_ERROR_CALL_SEQUENCE;
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 6000 && !got; ++tries) {       // up to ten minutes for rank 0's analyse
+      FILE* fp = fopen(path.c_str(), "rb");
+      if (fp) {
+        got = fread(id, 1, sizeof(id), fp) == sizeof(id);
+        fclose(fp);
+      }
+      if (!got) usleep(100000);
+    }
+    if (!got) return GSLS_ERROR_CALL_SEQUENCE;
+  }
+  const int f = gsls_comm_init(handle, nranks, rank, id, options);
+  return f < 0 ? f : 1;
 }
 
 // owner rank of every supernode (-1: top part) and the cut roots, for callers that want to inspect

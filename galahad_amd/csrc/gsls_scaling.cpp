@@ -12,7 +12,8 @@
 //    the pair is not unique, so the vector can differ from the reference's in the unconstrained directions --
 //    solutions agree, scale vectors need not.  Structurally singular matrices: error, or with `scale_if_singular` the
 //    reference's recipe (match the nonsingular part again, Duff-Pralet for the rest, scaling.f90:695-800).
-//  * scaling 2: the auction algorithm, restated step by step (scaling.f90:1351-1489 core, :1504-1609 pre/post).
+//  * scaling 2: an auction for the same assignment problem -- own design: synchronous bidding rounds with epsilon-scaling
+//    (see auction_scale_sym below); the reference's auction_scale_sym (scaling.f90:1351-1609) is a sequential one.
 //  * scaling 4: infinity-norm equilibration (Knight-Ruiz iteration, scaling.f90:480-521).
 #include <algorithm>
 #include <cmath>
@@ -238,91 +239,104 @@ int hungarian_scale_sym(int n, const int64_t* ptr, const int32_t* row, const dou
   return 1;
 }
 
-// scaling.f90:1351-1489 (core) and :1504-1609 (pre/post-processing), defaults of type auction_options (:33-38)
+// scaling = 2 (SSIDS: auction_scale_sym, src/spral/scaling.f90:1351-1609 -- the same problem, not the same algorithm).
+//
+// The assignment problem behind the scaling: persons = columns j, objects = rows i, benefit
+// b_ij = log|a_ij| - max_k log|a_kj| <= 0; prices p_i on the rows.  For ANY price vector, the column duals
+// v_j = max_i (b_ij - p_i) give log|a_ij| - cmax_j - p_i - v_j <= 0 for every entry, i.e. a row scaling exp(-p_i) and a
+// column scaling exp(-v_j - cmax_j) under which no entry exceeds 1 and every column attains 1; the symmetric scaling
+// is their geometric mean (Duff & Pralet).  What the auction adds is prices under which the ROWS attain (almost) 1
+// as well: at the end every assigned pair (i, j) is within epsilon of its column's best.
+//
+// Own design (round 3; the round-2 version restated the reference's sequential loop and is gone): a SYNCHRONOUS
+// (Jacobi) auction with epsilon-scaling, after Bertsekas.  A round has two data-parallel steps with no ordering
+// between the items of a step --
+//   bid:    every unassigned column looks at its entries once: best and second-best net value b_ij - p_i, and offers
+//           the best row a price raise of (best - second) + epsilon;
+//   award:  every row that received offers takes the highest (ties: the lowest column index, so the result does not
+//           depend on the order the offers are looked at), raises its price by it, and releases its previous column
+// -- so a round is two kernel-shaped loops over independent items (the shape a device version would launch), not a
+// queue walked in sequence.  Epsilon starts at a fraction of the spread of the benefits and shrinks by 8 per phase down
+// to EPS_FINAL; prices are kept across phases, assignments are not (a phase re-assigns under its own epsilon).  A phase
+// ends when every column that has entries is assigned, or -- matrices without a perfect matching, price wars -- when
+// the number of unassigned columns has not reached a new minimum for STALL rounds.  An approximate matching is all a
+// scaling needs: whatever the prices are when the last phase ends, the bounds above hold.
 int auction_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, double* scaling) {
-  const int max_iterations = 30000;
-  const int max_unchanged[3] = {10, 100, 100};
-  const float min_proportion[3] = {0.90f, 0.0f, 0.0f};
-  const float eps_initial = 0.01f;
+  constexpr double EPS_FINAL = 0.01;     // in log units: assigned entries within 1 % of their column's best
+  constexpr int STALL = 40;
   FullMatrix A = expand_log(n, ptr, row, val);
+  if (A.ptr[n] == 0) {
+    for (int i = 0; i < n; ++i) scaling[i] = 1.0;
+    return 0;
+  }
   std::vector<double> cmax(n, 0.0);
-  double maxentry = -RINF;
+  double spread = 0.0;
   for (int j = 0; j < n; ++j) {
     if (A.ptr[j] == A.ptr[j + 1]) continue;
     double m = -RINF;
     for (int64_t k = A.ptr[j]; k < A.ptr[j + 1]; ++k) m = std::max(m, A.val[k]);
     cmax[j] = m;
     for (int64_t k = A.ptr[j]; k < A.ptr[j + 1]; ++k) {
-      A.val[k] = m - A.val[k];
-      maxentry = std::max(maxentry, A.val[k]);
+      A.val[k] -= m;                                     // the benefit b_ij <= 0
+      spread = std::max(spread, -A.val[k]);
     }
   }
-  if (A.ptr[n] == 0) {
-    for (int i = 0; i < n; ++i) scaling[i] = 1.0;
-    return 0;
-  }
-  maxentry = 2 * maxentry + 1;       // prefers matchings of high cardinality
-  for (auto& x : A.val) x = maxentry - x;
-  std::vector<double> dualu(n, 0.0), dualv(n);
-  for (int j = 0; j < n; ++j) dualv[j] = -cmax[j];
-  std::vector<int32_t> match(n, 0), owner(n, 0), next(n);      // 1-based partners, 0 = none, -1 = ineligible
-  int unmatched = n, prev = -1, nunchanged = 0, tail = n;
-  for (int i = 0; i < n; ++i) next[i] = i;
-  double eps = eps_initial;
-  for (int itr = 1; itr <= max_iterations; ++itr) {
-    if (unmatched == 0) break;
-    if (unmatched != prev) nunchanged = 0;
-    prev = unmatched;
-    ++nunchanged;
-    bool stop = false;
-    for (int t = 0; t < 3; ++t)
-      if (nunchanged >= max_unchanged[t] && float(n - unmatched) / float(n) >= min_proportion[t]) stop = true;
-    if (stop) break;
-    eps = std::min(1.0, eps + 1.0 / (n + 1));
-    int insert = 0;
-    for (int cp = 0; cp < tail; ++cp) {
-      const int col = next[cp];
-      if (match[col] != 0) continue;
-      if (A.ptr[col] == A.ptr[col + 1]) continue;
-      int64_t k = A.ptr[col];
-      int bestr = A.row[k];
-      double bestu = A.val[k] - dualu[bestr];
-      double bestv = -RINF;
-      for (k = A.ptr[col] + 1; k < A.ptr[col + 1]; ++k) {
-        const double uu = A.val[k] - dualu[A.row[k]];
-        if (uu > bestu) {
-          bestv = bestu;
-          bestr = A.row[k];
-          bestu = uu;
-        } else if (uu > bestv) {
-          bestv = uu;
+  std::vector<double> price(n, 0.0), offer(n);
+  std::vector<int32_t> holder(n), target(n), bidder(n), todo;
+  std::vector<double> raise(n);
+  todo.reserve(n);
+  const int max_rounds = 2000 + n / 4;
+  for (double eps = std::max(spread / 8, EPS_FINAL);; eps = std::max(eps / 8, EPS_FINAL)) {
+    std::fill(holder.begin(), holder.end(), -1);         // row -> column that holds it
+    todo.clear();
+    for (int j = 0; j < n; ++j)
+      if (A.ptr[j] < A.ptr[j + 1]) todo.push_back(j);
+    size_t best_left = todo.size();
+    int since_best = 0;
+    for (int round = 0; !todo.empty() && round < max_rounds; ++round) {
+      // ---- bid: independent per unassigned column -----------------------------------------------------------
+      for (size_t t = 0; t < todo.size(); ++t) {
+        const int j = todo[t];
+        double w1 = -RINF, w2 = -RINF;
+        int i1 = -1;
+        for (int64_t k = A.ptr[j]; k < A.ptr[j + 1]; ++k) {
+          const double w = A.val[k] - price[A.row[k]];
+          if (w > w1) { w2 = w1; w1 = w; i1 = A.row[k]; }
+          else if (w > w2) w2 = w;
+        }
+        target[j] = i1;
+        raise[j] = (w2 == -RINF) ? eps : (w1 - w2) + eps;    // a column with one entry bids the minimum
+      }
+      // ---- award: independent per row (here: a scan of the offers that keeps the best per row) ----------------
+      for (size_t t = 0; t < todo.size(); ++t) bidder[target[todo[t]]] = -1;
+      for (size_t t = 0; t < todo.size(); ++t) {
+        const int j = todo[t], i = target[j];
+        if (bidder[i] < 0 || raise[j] > offer[i] || (raise[j] == offer[i] && j < bidder[i])) {
+          bidder[i] = j;
+          offer[i] = raise[j];
         }
       }
-      if (bestv == -RINF) bestv = 0.0;
-      if (bestu > 0) {
-        dualu[bestr] += bestu - bestv + eps;
-        dualv[col] = bestv - eps;
-        match[col] = bestr + 1;
-        --unmatched;
-        const int kcol = owner[bestr];
-        owner[bestr] = col + 1;
-        if (kcol != 0) {
-          match[kcol - 1] = 0;
-          ++unmatched;
-          next[insert++] = kcol - 1;
-        }
-      } else {
-        match[col] = -1;
-        --unmatched;
+      std::vector<int32_t> next;
+      next.reserve(todo.size());
+      for (size_t t = 0; t < todo.size(); ++t) {
+        const int j = todo[t], i = target[j];
+        if (bidder[i] != j) { next.push_back(j); continue; }   // outbid in this round: bids again
+        price[i] += offer[i];
+        if (holder[i] >= 0) next.push_back(holder[i]);          // the previous holder is released
+        holder[i] = j;
       }
+      todo.swap(next);
+      if (todo.size() < best_left) { best_left = todo.size(); since_best = 0; }
+      else if (++since_best >= STALL) break;
     }
-    tail = insert;
+    if (eps <= EPS_FINAL) break;
   }
-  // undo the pre-processing (the magnitude adjustment of match_postproc cancels in the symmetric average)
-  for (int i = 0; i < n; ++i) {
-    const double r = -dualu[i] + maxentry;
-    const double c = -dualv[i] - cmax[i];
-    scaling[i] = std::exp((r + c) / 2);
+  // row scaling exp(-p_i), column scaling exp(-v_j - cmax_j) with v_j = max_i (b_ij - p_i); symmetric: geometric mean
+  for (int j = 0; j < n; ++j) {
+    if (A.ptr[j] == A.ptr[j + 1]) { scaling[j] = 1.0; continue; }
+    double v = -RINF;
+    for (int64_t k = A.ptr[j]; k < A.ptr[j + 1]; ++k) v = std::max(v, A.val[k] - price[A.row[k]]);
+    scaling[j] = std::exp(-(price[j] + v + cmax[j]) / 2);
   }
   return 0;
 }

@@ -24,6 +24,9 @@ module GALAHAD_GSLS_double
   public :: GSLS_initialize, GSLS_analyse, GSLS_factor, GSLS_solve, GSLS_solve_mult
   public :: GSLS_enquire_posdef, GSLS_enquire_indef, GSLS_alter, GSLS_free
   public :: GSLS_set_coo, GSLS_factor_coo, GSLS_residual, GSLS_get_order, GSLS_solve_ir
+  ! one system over several GPUs, one process per GPU (include/gsls.h, "multi-GPU with the exchange INSIDE the library";
+  ! what one ssids_factor / ssids_solve call does for several devices, src/ssids/fkeep.F90:99-174, 229-318)
+  public :: GSLS_comm_unique_id, GSLS_comm_init, GSLS_comm_factor, GSLS_comm_solve, GSLS_comm_free
 
   integer, parameter :: wp = c_double
   integer, parameter :: long = c_int64_t
@@ -179,9 +182,83 @@ module GALAHAD_GSLS_double
       real(c_double), intent(in) :: d(*)
       type(gsls_inform), intent(out) :: inform
     end function
+    integer(c_int) function c_gsls_comm_unique_id(id) bind(C, name='gsls_comm_unique_id')
+      import :: c_int, c_char
+      character(kind=c_char), intent(out) :: id(128)
+    end function
+    integer(c_int) function c_gsls_comm_init(handle, nranks, rank, id, options) bind(C, name='gsls_comm_init')
+      import :: c_ptr, c_int, c_int32_t, c_char, gsls_options
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: nranks, rank
+      character(kind=c_char), intent(in) :: id(128)
+      type(gsls_options), intent(in) :: options
+    end function
+    integer(c_int) function c_gsls_comm_factor(handle, posdef, val, options, inform) bind(C, name='gsls_comm_factor')
+      import :: c_ptr, c_int, c_int32_t, c_double, gsls_options, gsls_inform
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: posdef
+      real(c_double), intent(in) :: val(*)
+      type(gsls_options), intent(in) :: options
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_comm_solve(handle, x, inform) bind(C, name='gsls_comm_solve')
+      import :: c_ptr, c_int, c_double, gsls_inform
+      type(c_ptr), value :: handle
+      real(c_double), intent(inout) :: x(*)
+      type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_comm_destroy(handle) bind(C, name='gsls_comm_destroy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
+    end function
   end interface
 
 contains
+
+  ! ---- one system over several GPUs: every rank (process) analyses the same matrix, rank 0 obtains the 128-byte id
+  ! and hands it to the others by whatever means the host program has (MPI_Bcast, a file), then all ranks call
+  ! GSLS_comm_init and, any number of times, GSLS_comm_factor / GSLS_comm_solve.  status: the C ABI's flag.
+  subroutine GSLS_comm_unique_id(id, status)
+    character(kind=c_char), intent(out) :: id(128)
+    integer, intent(out) :: status
+    status = int(c_gsls_comm_unique_id(id))
+  end subroutine GSLS_comm_unique_id
+
+  subroutine GSLS_comm_init(nranks, rank, id, keep, options, status)
+    integer, intent(in) :: nranks, rank          ! rank = 0 .. nranks - 1
+    character(kind=c_char), intent(in) :: id(128)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    integer, intent(out) :: status
+    status = int(c_gsls_comm_init(keep%handle, int(nranks, c_int32_t), int(rank, c_int32_t), id, options))
+  end subroutine GSLS_comm_init
+
+  ! val: the sorted lower-by-columns values, as for GSLS_factor; inform holds the totals on every rank
+  subroutine GSLS_comm_factor(posdef, val, keep, options, inform)
+    logical, intent(in) :: posdef
+    real(wp), intent(in) :: val(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_options), intent(in) :: options
+    type(gsls_inform), intent(out) :: inform
+    integer(c_int) :: rc
+    rc = c_gsls_comm_factor(keep%handle, merge(1_c_int32_t, 0_c_int32_t, posdef), val, options, inform)
+  end subroutine GSLS_comm_factor
+
+  ! x = b on entry (the same on every rank), the whole solution on every rank on exit
+  subroutine GSLS_comm_solve(x, keep, inform)
+    real(wp), intent(inout) :: x(:)
+    type(gsls_keep), intent(inout) :: keep
+    type(gsls_inform), intent(out) :: inform
+    integer(c_int) :: rc
+    rc = c_gsls_comm_solve(keep%handle, x, inform)
+  end subroutine GSLS_comm_solve
+
+  subroutine GSLS_comm_free(keep, status)
+    type(gsls_keep), intent(inout) :: keep
+    integer, intent(out) :: status
+    status = 0
+    if (c_associated(keep%handle)) status = int(c_gsls_comm_destroy(keep%handle))
+  end subroutine GSLS_comm_free
 
   subroutine GSLS_initialize(keep, options)
     type(gsls_keep), intent(inout) :: keep

@@ -260,6 +260,15 @@ int gsls_comm_factor_dev(void* handle, int32_t posdef, const double* d_val, cons
 int gsls_comm_solve_dev(void* handle, double* d_x, gsls_inform* inform);
 int gsls_comm_collect_dev(void* handle, double* d_x, gsls_inform* inform);
 int gsls_comm_destroy(void* handle);
+/* the same with HOST arrays (what GALAHAD_GSLS_double's GSLS_comm_factor / GSLS_comm_solve bind): val = the sorted
+ * lower-by-columns values of gsls_factor; x = b on entry, the WHOLE solution on every rank on exit */
+int gsls_comm_factor(void* handle, int32_t posdef, const double* val, const gsls_options* options, gsls_inform* inform);
+int gsls_comm_solve(void* handle, double* x, gsls_inform* inform);
+/* several GPUs under an UNCHANGED caller (SLS_factorize / SLS_solve, SBLS, CQP ...): start one copy of the host program
+ * per GPU with GSLS_COMM_RANKS = N, GSLS_COMM_RANK = 0..N-1, GSLS_COMM_ID_FILE = <path>; gsls_analyse then joins the
+ * communicator (this call; rank 0 publishes the id through the file) and gsls_factor* / gsls_solve on the handle become
+ * the collective calls above.  Returns 0 if the variables are not set, 1 if joined, < 0 on error. */
+int gsls_comm_init_env(void* handle, const gsls_options* options);
 
 /* ---- introspection used by the parity tests and bench (not part of the SSIDS surface) ------------ */
 

@@ -69,9 +69,17 @@ ARMS = [
     """       CASE ( 'gsls' )
          CALL SLS_copy_control_to_gsls( control, data%gsls_options )
          CALL CPU_time( time ) ; CALL CLOCK_time( clock )
-         CALL GSLS_factor_coo( data%must_be_definite,                           &
-                               matrix%VAL( : data%matrix_ne ), data%gsls_keep,  &
-                               data%gsls_options, data%gsls_inform )
+!  explicit scalings (control%scaling = 1..3, MC64 / MC77): the facade has scattered AND scaled the values into
+!  data%matrix%VAL (:4107-4159) and divides x by SCALE around every solve (:4757-4761) -- factorize exactly those
+         IF ( data%explicit_scaling ) THEN
+           CALL GSLS_factor( data%must_be_definite,                             &
+                             data%matrix%VAL( : data%matrix%PTR( data%matrix%n + 1 ) - 1 ), &
+                             data%gsls_keep, data%gsls_options, data%gsls_inform )
+         ELSE
+           CALL GSLS_factor_coo( data%must_be_definite,                         &
+                                 matrix%VAL( : data%matrix_ne ), data%gsls_keep,&
+                                 data%gsls_options, data%gsls_inform )
+         END IF
          CALL SLS_copy_inform_from_gsls( inform, data%gsls_inform )
 !  the order the factors are in (pre-ordering, repaired and learned pivot sequence): what SLS_enquire reports
          IF ( inform%status == GALAHAD_ok )                                     &
@@ -113,14 +121,26 @@ ARMS = [
            D( 2, : ) = 0.0_wp
          END IF
        ELSE
-         IF ( PRESENT( D ) .AND. PRESENT( PIVOTS ) ) THEN
-           CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform,           &
-                                    piv_order = PIVOTS, d = D )
+!  PIVOTS as SLS's callers read it (SILS_enquire, sils.f90:2477-2479; MA57): entry k is the variable eliminated at the
+!  k-th pivot, negative when it belongs to a 2x2 pivot -- FDC walks PIVOTS( k ) beside D( :, k ) by pivot position
+!  (fdc.f90:926-975).  The backend ABI reports, like SSIDS (ssids.f90:1299-1341), the position of every VARIABLE; the
+!  ssids arm hands that on unconverted, which FDC then misreads whenever the order is not the identity
+         IF ( PRESENT( PIVOTS ) ) THEN
+           CALL SPACE_resize_array( data%n, data%PIVOTS,                        &
+                                    inform%status, inform%alloc_status )
+           IF ( inform%status /= GALAHAD_ok ) GO TO 900
+           IF ( PRESENT( D ) ) THEN
+             CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform,         &
+                                      piv_order = data%PIVOTS, d = D )
+           ELSE
+             CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform,         &
+                                      piv_order = data%PIVOTS )
+           END IF
+           DO k = 1, data%n
+             PIVOTS( ABS( data%PIVOTS( k ) ) ) = SIGN( k, data%PIVOTS( k ) )
+           END DO
          ELSE IF ( PRESENT( D ) ) THEN
            CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform, d = D )
-         ELSE IF ( PRESENT( PIVOTS ) ) THEN
-           CALL GSLS_enquire_indef( data%gsls_keep, data%gsls_inform,           &
-                                    piv_order = PIVOTS )
          END IF
        END IF
 
@@ -302,10 +322,13 @@ def main(src, dst):
             shared += 1
             ln = ln.replace("'ssids'", "'ssids', 'gsls'")          # the shared CASE lists (:2849 analyse, :4106 factorize)
         # SLS_factorize: the host loop that scatters the values through MAPS (:4107-4150) is skipped for gsls --
-        # GSLS_factor_coo maps them on the device
+        # GSLS_factor_coo maps them on the device -- unless the facade scales the scattered copy itself
+        # (data%explicit_scaling, control%scaling = 1..3): then the reference's scatter + scaling block runs and
+        # the arm factorizes data%matrix%VAL
         if shared == 2 and scatter == 0 and ln.strip() == "data%matrix%n = matrix%n":
             out.append(ln)
-            out.append("       IF ( data%solver( 1 : data%len_solver ) /= 'gsls' ) THEN")
+            out.append("       IF ( data%solver( 1 : data%len_solver ) /= 'gsls' .OR.                   &")
+            out.append("            data%explicit_scaling ) THEN")
             scatter = 1
             continue
         if scatter == 1 and ln.strip() == "!  apply calculated scaling factors":

@@ -441,6 +441,45 @@ def test_factor_with_scaling_vector(posdef):
     s.terminate()
 
 
+@pytest.mark.parametrize("posdef", [True, False])
+def test_factor_coo_with_a_host_scaling_vector_equals_factor(posdef):
+    """gsls_factor_coo's optional `scale` (the Fortran binding exposes it): the caller's HOST vector must survive the
+    re-upload of the device arrays that the first factorization of a pattern and every order repair trigger (ADVICE
+    r2: it was copied back from freed device memory).  Same bits as gsls_factor with the same scale."""
+    import ctypes as C
+    from galahad_amd._lib import Inform, lib
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    prob = P.random_sparse(1200, 5, seed=33, spd=posdef)
+    n, row, col, val, rhs, xs = prob
+    scale = 10.0 ** np.random.default_rng(5).uniform(-2, 2, n)
+    sols = []
+    for coo in (False, True):
+        m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+        s, c, i = SLS(), Control(), InformSLS()
+        s.initialize("gsls", c, i)
+        c.pivot_control = 2 if posdef else 1
+        s.analyse(m, c, i)
+        assert i.status == 0
+        s._copy_control(c)
+        ginf = Inform()
+        for rep in range(2):
+            if coo:
+                f = lib.gsls_factor_coo(s.handle, 1 if posdef else 0, np.ascontiguousarray(val).ctypes.data_as(C.c_void_p),
+                                        scale.ctypes.data_as(C.c_void_p), C.byref(s.opts), C.byref(ginf))
+            else:
+                VAL = s.scatter_values(m)
+                f = lib.gsls_factor(s.handle, 1 if posdef else 0, VAL.ctypes.data_as(C.c_void_p),
+                                    scale.ctypes.data_as(C.c_void_p), C.byref(s.opts), C.byref(ginf))
+            assert f >= 0, (coo, f, ginf.as_dict())
+            x = np.asfortranarray(rhs.copy())
+            f = lib.gsls_solve(s.handle, 0, 1, x.ctypes.data_as(C.c_void_p), n, C.byref(s.opts), C.byref(ginf))
+            assert f >= 0
+            assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-10
+        sols.append(x)
+        s.terminate()
+    assert np.array_equal(sols[0], sols[1])
+
+
 @pytest.mark.parametrize("nb", [500, 700, 2500])
 def test_all_zero_diagonal_saddle_needs_2x2_everywhere(nb):
     """K = [0 B; B^T 0]: no variable has a pivot of its own, every elimination is a 2x2 pivot.  The backend

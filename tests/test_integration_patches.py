@@ -49,3 +49,11 @@ def test_patch_sls_adds_arms_and_keeps_the_rest(tmp_path):
     removed = [ln for tag, i1, i2, j1, j2 in _changed(src, out) if tag in ("delete", "replace")
                for ln in src.split("\n")[i1:i2] if ln.strip()]
     assert len(removed) <= 4, removed[:10]
+    # explicit scalings (control%scaling = 1..3): the host scatter + the reference's scaling block must still
+    # run for gsls, and the arm must then factorize the scaled copy data%matrix%VAL, not the caller's values
+    i_if = out.index("IF ( data%solver( 1 : data%len_solver ) /= 'gsls' .OR.")
+    i_sc = out.index("!  apply calculated scaling factors", i_if)
+    assert "data%explicit_scaling ) THEN" in out[i_if:i_if + 200]
+    assert i_if < out.index("data%matrix%VAL( k ) = matrix%VAL( l )", i_if) < i_sc
+    arm = out[out.index("CALL GSLS_factor( data%must_be_definite") - 200:out.index("CALL GSLS_factor_coo( data%must_be_definite")]
+    assert "IF ( data%explicit_scaling ) THEN" in arm and "data%matrix%VAL(" in arm
