@@ -24,8 +24,15 @@ if [ ! -d "$REF/src/ssids" ]; then
   echo "build_ref: $REF not present -- keeping whatever prebuilt files are in $OUT" >&2
   exit 0
 fi
-W=$(mktemp -d /tmp/gsls_ref_build.XXXXXX)
-trap 'rm -rf "$W"' EXIT
+# (development aid: GSLS_REF_SCRATCH=<dir> keeps the scratch directory and reuses the reference objects in it, so that
+#  a change to the drop-in part below does not recompile LAPACK and SSIDS)
+if [ -n "${GSLS_REF_SCRATCH:-}" ]; then
+  W=$GSLS_REF_SCRATCH
+  mkdir -p "$W"
+else
+  W=$(mktemp -d /tmp/gsls_ref_build.XXXXXX)
+  trap 'rm -rf "$W"' EXIT
+fi
 mkdir -p "$OUT" "$W/inc/ssids/cpu/kernels" "$W/inc/hw_topology" "$W/mod" "$W/obj"
 S=$REF/src
 
@@ -35,6 +42,7 @@ OPT=${GSLS_REF_OPT:--O2}
 FFLAGS="$OPT -fopenmp -fPIC -module-dir $W/mod -I$W/mod"
 CXXFLAGS="-std=c++11 $OPT -fopenmp -fPIC -I$W/inc"
 
+if [ ! -f "$W/.reference_objects_done" ]; then
 # ---- header layout (scratch only) -------------------------------------------------------------
 cp $S/ssids/cpu/*.hxx            $W/inc/ssids/cpu/
 cp $S/ssids/cpu/kernels/*.hxx    $W/inc/ssids/cpu/kernels/
@@ -101,12 +109,29 @@ for f in lmt/lmt.f90 qpt/qpt.f90 roots/roots.f90 norms/norms.f90 gls/gls.f90 dum
 for f in dum/ma33d.f dum/mc13d.f dum/mc21d.f dum/mc22d.f dum/mc23d.f dum/mc29d.f \
          dum/mc30d.f ; do ff $f ; done
 wait $p1 $p2 $p3
+touch "$W/.reference_objects_done"
+fi
 
 # ---- link ------------------------------------------------------------------------------------------
 $FC -fopenmp -shared -o $OUT/libgalahad_ref.so $W/obj/*.o -lstdc++
 $FC $FFLAGS -o $OUT/ref_driver $HERE/ref_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
 $FC $FFLAGS -o $OUT/sbls_driver $HERE/sbls_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
 $FC $FFLAGS -o $OUT/trs_driver $HERE/trs_driver.f90 -L$OUT -lgalahad_ref -Wl,-rpath,'$ORIGIN' -lstdc++
+# second CPU baseline: the same reference library with the optimised OpenBLAS inside scipy behind SSIDS' seven BLAS /
+# LAPACK calls (oracle/blas_shim.c, used through LD_PRELOAD by oracle/refio.py run(..., blas="openblas"))
+OB=$(python3 - <<'PYEOF'
+import glob, os
+try:
+    import scipy
+    c = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
+    print(os.path.realpath(c[0]) if c else "")
+except Exception:
+    print("")
+PYEOF
+)
+if [ -n "$OB" ]; then
+  gcc -O2 -shared -fPIC -o $OUT/libblas_shim.so $HERE/blas_shim.c "$OB" -Wl,-rpath,"$(dirname "$OB")"
+fi
 echo "build_ref: wrote $OUT/libgalahad_ref.so and $OUT/ref_driver"
 
 # ---- drop-in build: the REAL SLS facade with the gsls arms of INTEGRATION.md, linked to the MI355X
@@ -169,5 +194,42 @@ if [ -f "$GSLS_LIB" ]; then
       -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' \
       -lstdc++ -lm 2>$W/link.log || { cat $W/link.log; exit 1; }
   done
-  echo "build_ref: wrote $OUT/sls_gsls_driver, sbls_gsls_driver, trs_gsls_driver, slst_c_gsls (GALAHAD SLS/SBLS/TRS + gsls backend)"
+  # SBLS's interface layer.  The C interface itself (src/sbls/C/sbls_ciface.f90 behind include/sbls.h) cannot be built
+  # in this tree: it USEs GALAHAD_ULS_double_ciface -> HSL_MA48_double_ciface (src/dum/C/hsl_ma48d_ciface.f90:15,20),
+  # which imports ma48_get_perm and ma48_determinant -- procedures the tree's own dummy src/dum/hsl_ma48d.f90 does not
+  # define (HSL MA48 itself is not here, and no stand-in is written).  What sbls_ciface.f90 wraps, one call each, is
+  # SBLS's "simple" interface (SBLS_import / SBLS_factorize_matrix / SBLS_solve_system / SBLS_information on
+  # SBLS_full_data_type); the reference's own test of THAT layer, src/sbls/sblsti.f90 -- the same seven storage
+  # schemes and data as src/sbls/C/sblst.c, expected residuals in src/sbls/sblsdt.output -- is built above the
+  # patched SBLS and SLS, the solver named through oracle/select_solver.py.
+  python3 $HERE/select_solver.py $S/sbls/sblsti.f90 $W/sblsti_sel.f90 SBLS
+  $FC $F2 -o $OUT/sblsti_gsls $W/sblsti_sel.f90 $W/obj2_sbls.o \
+      $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  # The callers' own spec-sheet examples, whose stored outputs the reference holds (tests/golden/*.output are copies of
+  # those data files): src/cqp/cqps.f90 (cqpds.output), src/rqs/rqss.f90 (rqsds.output), src/trs/trss.f90
+  # (trsds.output), compiled where they lie with the solver named through oracle/select_solver.py
+  $FC $F2 -c -o $W/obj2_rqs.o $S/rqs/rqs.f90
+  python3 $HERE/select_solver.py $S/cqp/cqps.f90 $W/cqps_sel.f90 CQP
+  python3 $HERE/select_solver.py $S/rqs/rqss.f90 $W/rqss_sel.f90 RQS
+  python3 $HERE/select_solver.py $S/trs/trss.f90 $W/trss_sel.f90 TRS
+  $FC $F2 -o $OUT/cqps_gsls $W/cqps_sel.f90 $W/obj2_q_*.o $W/obj2_sbls.o \
+      $W/obj2_sls_gsls.o $W/obj2_hsl_ma86d_v2.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  $FC $F2 -o $OUT/rqss_gsls $W/rqss_sel.f90 $W/obj2_rqs.o $W/obj2_ir.o \
+      $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  $FC $F2 -o $OUT/trss_gsls $W/trss_sel.f90 $W/obj2_trs.o $W/obj2_ir.o \
+      $W/obj2_sls_gsls.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  # BASELINE.json configs[0] as the reference runs it (src/cqp/makemaster:57 QPLIB_EXAMPLE = QPBAND.qplib; bin/dgal):
+  # the reference's main program for QPLIB input, src/cqp/incqp.f90 (RPD reads the problem from unit 5, the solvers
+  # come from the spec file RUNCQP.SPC in the working directory), compiled where it lies above the patched facade
+  for f in copyright/copyright scaling/scaling ; do
+    $FC $F2 -c -o $W/obj2_q2_$(basename $f).o $S/$f.f90
+  done
+  $FC $F2 -o $OUT/runcqp_qplib_gsls $S/cqp/incqp.f90 $W/obj2_q2_*.o $W/obj2_q_*.o $W/obj2_sbls.o \
+      $W/obj2_sls_gsls.o $W/obj2_hsl_ma86d_v2.o $W/obj2_gsls_iface.o -L$OUT -lgalahad_ref -L$HERE/../galahad_amd -lgsls \
+      -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../galahad_amd' -lstdc++
+  echo "build_ref: wrote $OUT/sls_gsls_driver, sbls_gsls_driver, trs_gsls_driver, slst_c_gsls, sblsti_gsls (GALAHAD SLS/SBLS/TRS + gsls backend)"
 fi
