@@ -56,6 +56,9 @@ struct Handle {
   bool coo_uploaded = false;      // ... and its structure is on the device
   std::vector<int32_t> coo_row, coo_col, coo_map;
   int shard_repairs = 0;          // repair rounds of the sharded path (plan_repair's pass counter)
+  int learn_strikes = 0;          // factorizations in a row whose learned pivot sequence failed on the new values
+  int tpp_useless = 0;            // flag-only repairs in a row after which every flagged column failed again
+  bool eager_delay = false;       // ... twice: failing columns of one-block fronts go straight to the parent
   // in-library exchange (gsls_comm_*): one RCCL communicator per handle, buffers on the handle's device
   ncclComm_t comm = nullptr;
   int comm_ranks = 0, comm_rank = 0;
@@ -158,9 +161,16 @@ struct RepairPlan {
 // again: to the root of its tree, where k_front_tpp cannot fail -- the delayed pivot that rides all the way up);
 // partner[v]: the variable v was matched with when the values arrived (zero-diagonal pairs, see
 // refine_order_with_values), -1 if none: a pair travels together, or the one left behind fails next.
+// eager: whole-front pivoting has not rescued anything on this handle so far (every flagged column failed again): a
+//        column that fails in a front of ONE 64-column block -- where the blocked kernel's complete pivoting has
+//        already seen every fully-summed column -- is flagged AND moved to the parent in the same repair (one pass
+//        per level of a delay cascade instead of two);
+// to_root: last resort (the pass budget is used up, or nothing else is left to change): every failing variable goes to
+//        the root of its tree, where k_front_tpp accepts what is left as zero pivots -- never an error for a matrix
+//        that has a factorization.
 RepairPlan plan_repair(const Symbolic& S, const std::vector<int32_t>& failed_pos, std::vector<uint8_t>& tppvar,
                        std::vector<uint8_t>& tppfail, std::vector<uint8_t>& force,
-                       const std::vector<int32_t>& partner, int pass) {
+                       const std::vector<int32_t>& partner, int pass, bool eager = false, bool to_root = false) {
   RepairPlan rp;
   const int n = S.n, nn = S.nnodes;
   if (int(tppvar.size()) != n) tppvar.assign(n, 0);
@@ -177,7 +187,7 @@ RepairPlan plan_repair(const Symbolic& S, const std::vector<int32_t>& failed_pos
     const int s = int(std::upper_bound(S.sptr.begin(), S.sptr.begin() + nn + 1, p) - S.sptr.begin()) - 1;
     if (s < 0 || s >= nn) continue;
     const int v = S.invp[p];
-    if (!nodeflag[s]) {
+    if (!nodeflag[s] && !to_root && !(eager && S.ncol(s) <= NB && S.sparent[s] < nn)) {
       // the blocked kernels failed here
       const int blk = (p - S.sptr[s]) / NB, nblk = (S.ncol(s) + NB - 1) / NB;
       if (S.ncol(s) > TPP_WIDE && pass < 6) {
@@ -199,6 +209,7 @@ RepairPlan plan_repair(const Symbolic& S, const std::vector<int32_t>& failed_pos
       if (S.sparent[s] >= nn) continue;
       int anc = S.sparent[s];
       if (tppfail[v] < 255) ++tppfail[v];
+      if (to_root && tppfail[v] < 2) tppfail[v] = 2;
       if (tppfail[v] > 1)
         while (S.sparent[anc] < nn) anc = S.sparent[anc];
       const double k2 = double(S.sptr[anc + 1] - 1) + 0.5;
@@ -701,6 +712,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   bool tiny_off = false;
   int tiny_repeats = 0;
   const int max_pass = 60;    // a variable fails at most three times (plan_repair); cascades end long before this
+  int pending_flags = 0;      // columns the last repair flagged for whole-front pivoting (without moving them)
   for (int pass = 0;; ++pass) {
     // refactorizations of a learned order: tiny fronts whole, a wave each (k_front_tiny); if that kernel
     // meets a pivot it cannot take (stat[13]) the pass is repeated on the workgroup path
@@ -769,7 +781,19 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     }
     if (getenv("GSLS_DEBUG"))
       fprintf(stderr, "[gsls] pass %d (tiny %d ready %d strikes %d): blocks fast %d, pivoted %d, tpp fronts %d (left %d), failed columns %d, 2x2 %d | why: small %d inblock %d straddle %d rej2x2 %d below %d\n", pass, int(use_tiny), int(h->tiny_ready), h->tiny_strikes, st[6], st[7], st[14], st[15], st[4], st[3], st[8], st[9], st[10], st[11], st[12]);
-    if (!posdef && st[4] == 0 && h->learned < 3 && (st[7] > 0 || st[14] > 0)) {
+    if (pass == 0 && !posdef) {
+      // a learned pivot sequence that the next values break at once (interior-point iterations late in a run) is not
+      // worth learning again: two such starts in a row and this handle stops spending passes on it
+      if (st[4] > 0 && h->learned > 0) ++h->learn_strikes;
+      else if (st[4] == 0) h->learn_strikes = 0;
+    }
+    if (pending_flags > 0) {
+      // the last repair only flagged fronts for whole-front pivoting: did that rescue anything?
+      if (st[15] * 10 >= pending_flags * 9) { if (++h->tpp_useless >= 2) h->eager_delay = true; }
+      else h->tpp_useless = 0;
+      pending_flags = 0;
+    }
+    if (!posdef && st[4] == 0 && h->learned < 3 && h->learn_strikes < 2 && (st[7] > 0 || st[14] > 0)) {
       // ---- learn: fold the pivot sequence the pivoting kernels chose inside their blocks / fronts into the
       // elimination order, and remember where they took 2x2 pivots, so that later factorizations of
       // this pattern (the next interior-point iterations) go through the optimistic kernel
@@ -842,13 +866,20 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     }
     std::sort(failed.begin(), failed.end());
     failed.erase(std::unique(failed.begin(), failed.end()), failed.end());
-    RepairPlan rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, pass);
+    RepairPlan rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, pass, h->eager_delay);
     if (pass >= max_pass || (!rp.reorder && !rp.flagged)) {
-      inform->num_delay = total_moved;
-      inform->flag = GSLS_ERROR_UNIMPLEMENTED;   // not reached in any test: every failing variable ends at a root
-      inform->time_factor = now() - t0;
-      return inform->flag;
+      // last resort: every failing variable to the root of its tree (k_front_tpp takes what cannot be eliminated
+      // there as zero pivots: warning 7 and a rank below n, as the reference reports a singular matrix) -- a matrix
+      // that has a factorization never leaves here with an error
+      rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, pass, h->eager_delay, true);
+      if (pass >= max_pass + 8 || (!rp.reorder && !rp.flagged)) {
+        inform->num_delay = total_moved;
+        inform->flag = GSLS_ERROR_UNKNOWN;         // (an internal inconsistency, not a property of the matrix)
+        inform->time_factor = now() - t0;
+        return inform->flag;
+      }
     }
+    if (rp.flagged && !rp.reorder) pending_flags = int(failed.size());
     total_moved += int(failed.size());
     h->tiny_ready = false;
     h->tiny_black.clear();
@@ -1348,8 +1379,11 @@ int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed_in, i
   std::vector<int32_t> failed(failed_in, failed_in + nfailed);
   std::sort(failed.begin(), failed.end());
   failed.erase(std::unique(failed.begin(), failed.end()), failed.end());
-  RepairPlan rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, h->shard_repairs++);
-  if (!rp.reorder && !rp.flagged) return GSLS_ERROR_UNIMPLEMENTED;
+  const int round = h->shard_repairs++;
+  RepairPlan rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, round);
+  if (round >= 40 || (!rp.reorder && !rp.flagged))       // last resort, as in gsls_factor: to the roots (zero pivots there)
+    rp = plan_repair(h->S, failed, h->tppvar, h->tppfail, h->force, h->partner, round, false, true);
+  if (!rp.reorder && !rp.flagged) return GSLS_ERROR_UNKNOWN;
   const int nranks = h->S.nranks, rank = h->F.myrank;
   if (rp.reorder) {
     const int flag = reanalyse(h, rp.order, nullptr);
@@ -1552,7 +1586,8 @@ int gsls_comm_factor_dev(void* handle, int32_t posdef, const double* d_val, cons
     return inform->flag;
   }
   inform->time_factor = now() - t0;
-  return inform->flag = GSLS_ERROR_UNIMPLEMENTED;
+  return inform->flag = GSLS_ERROR_UNKNOWN;      // (60 collective repair rounds: gsls_shard_repair sends everything
+                                                 //  that still fails to the roots from round 40 on)
 }
 
 // One full solve (job 0, one right-hand side): d_x holds b on every rank on entry; on exit the entries of the

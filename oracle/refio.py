@@ -5,6 +5,7 @@ The binary layout is documented at the top of oracle/ref_driver.f90.
 """
 import os
 import struct
+import sys
 import subprocess
 import tempfile
 
@@ -250,6 +251,8 @@ def run_cqp(n, m, H, A, g, c_l, c_u, x_l, x_u, *, solver="gsls", print_level=0, 
             raise RuntimeError("cqp driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
         if print_level:
             print(p.stdout)
+        if os.environ.get("GSLS_DEBUG"):        # the backend's diagnostics (passes per factorization ...)
+            sys.stderr.write(p.stderr)
         buf = open(pout, "rb").read()
         ints = np.frombuffer(buf, dtype="<i4", count=4)
         reals = np.frombuffer(buf, dtype="<f8", count=7, offset=16)
