@@ -58,9 +58,11 @@ __global__ void k_scatter_a(int64_t cnt, const int64_t* __restrict__ asrc,
   int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   for (; i < cnt; i += stride) {
+    const int64_t d = adst[i];
+    if (d < 0) continue;            // (a sharded run: the entry belongs to a front another rank owns)
     double v = val[asrc[i]];
     if (scale) v *= scale[invp[arow[i]]] * scale[invp[acol[i]]];
-    L[adst[i]] = v;
+    L[d] = v;
   }
 }
 
@@ -806,11 +808,7 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLis
         f[j * (m - 1) - j * (j - 1) + lane - r0] = e;
       }
     }
-    const int ri = lane >> 1, q = n >> 1;
-    double* bk = Lbk + t.lboff + 2 * ((ri <= q) ? ri * ri : q * q + (ri - q) * n) + (lane & 1);
-#pragma unroll
-    for (int k = 0; k < NC; ++k)
-      if (k < n && lane > k && lane < m) bk[2 * k] = v[k];
+    // (the backward sweep reads this image too and transposes it in LDS: no second image, wave_bwd_transpose)
   } else {
     double* Lb = L + t.loff;
 #pragma unroll
@@ -2841,7 +2839,8 @@ k_big_bwd_trsv(const NodeDesc* __restrict__ nodes, const BigTrsv* __restrict__ t
 // Per front the arithmetic is the tiny kernels': right-hand side + (sum of the children's contributions), the
 // recurrences column by column.
 // =================================================================================================
-enum { WT_PULL = 1, WT_INT = 2, WT_PUSH = 4, WT_ZVEC = 8 };
+enum { WT_PULL = 1, WT_INT = 2, WT_PUSH = 4, WT_ZVEC = 8,
+       WT_DENSE = 16 };   // (with WT_PULL) every row has at most two sources: goff indexes the dense table wpull2
 struct WTask {
   int32_t m, n, sptr, flags;   // WT_PULL: children in earlier stages (gather lists); WT_INT: children in this group
                                // (LDS accumulator); WT_PUSH: the parent is in this group; WT_ZVEC: the parent is in a
@@ -3049,15 +3048,33 @@ __device__ __forceinline__ void wave_fwd_arrive(const WTask& t, int lane, const 
 
 // slotv != nullptr: the result goes there by pivot slot (job ALL: only the backward wave kernels read it);
 // otherwise to xp by position, like every other kernel's
+// Pulls with at most two sources per row (WT_DENSE: every front of the metric workload's upper stages): the sources'
+// indices sit in a dense table, one 8-byte pair per row at a place the task record gives, so the pair is ONE hop and
+// is requested before the image (wave_pull2_issue, ahead of wave_fwd_load), the two contribution entries a second hop
+// that overlaps the image's arrival -- against gth_ptr -> gth_src -> cvec, three dependent round trips AFTER it.
+typedef int int2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int2_t wave_pull2_issue(const WTask& t, int lane, const int32_t* __restrict__ pull2) {
+  int2_t r = {-1, -1};
+  if ((t.flags & (WT_PULL | WT_DENSE)) == (WT_PULL | WT_DENSE)) {          // (uniform)
+    r = __builtin_bit_cast(int2_t, __builtin_amdgcn_raw_buffer_load_b64(wave_rsrc(pull2 + 2 * t.goff, t.m * 8), lane * 8, 0, 0));
+    if (lane >= t.m) r = int2_t{-1, -1};                                   // (the descriptor returned zeros there)
+  }
+  return r;
+}
+
 template <int NN, bool APPLY_D, bool PULLS, int AS = 64>     // AS: row length of the LDS accumulators (>= every m of the launch)
 __device__ __forceinline__ void wave_fwd_compute(const WTask& t, int lane, const WFwdPre<NN>& p, double* __restrict__ acc,
                                                  const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
                                                  double* __restrict__ xp, double* __restrict__ slotv,
-                                                 double* __restrict__ cvec) {
+                                                 double* __restrict__ cvec, int2_t pull = int2_t{-1, -1}) {
   const int m = t.m, n = t.n;
   // analyse-time row `lane` of the front: right-hand side + (sum of the children's contributions)
   double csum = 0.0;
-  if (PULLS && (t.flags & WT_PULL)) {   // (wave-uniform: every lane walks the loop, rows without sources add nothing)
+  if (PULLS && (t.flags & WT_PULL) && (t.flags & WT_DENSE)) {
+    const double c0 = cvec[max(pull.x, 0)], c1 = cvec[max(pull.y, 0)];
+    csum += (pull.x >= 0) ? c0 : 0.0;      // list order, as the general form below
+    csum += (pull.y >= 0) ? c1 : 0.0;
+  } else if (PULLS && (t.flags & WT_PULL)) {   // (wave-uniform: every lane walks the loop, rows without sources add nothing)
     const int lr = min(lane, m - 1);
     const int g0 = gth_ptr[t.goff + lr], g1 = (lane < m) ? gth_ptr[t.goff + lr + 1] : g0;
     const int last = max(g1 - 1, g0);   // (g0 is a valid index whenever the front has any source at all)
@@ -3124,22 +3141,66 @@ struct WBwdPre {
 };
 
 // FAST: the one-hop forms only (job ALL on the tier's own data; see above), branch-free like wave_fwd_load
+// ONE image serves both sweeps (round 3): the backward step reads the forward image Lf -- column pairs by rows, the layout
+// the factorization kernels' registers have -- as the same flat stream and takes its TRANSPOSE out of LDS: lane k =
+// column k reads (L(2i,k), L(2i+1,k)) for the row pairs i, two 8-byte LDS reads 16 bytes apart (one ds_read2_b64) where
+// the second image had one 16-byte read.  The factorization writes 168 MB less per step, and what both sweeps stream is
+// half as large as the Infinity Cache instead of larger than it.
+__device__ __forceinline__ int wf_image_bytes(int m, int n) {
+  const int npair = (n + 1) >> 1;
+  return 16 * (npair * (m - 1) - npair * (npair - 1));
+}
+// entry (row r, column k), r > k, of the forward image as an index of doubles: 2 * (j (m - j - 2) + r - 1) + (k & 1), j = k / 2
+__device__ __forceinline__ int wf_col_base(int k, int m) {
+  const int j = k >> 1;
+  return 2 * (j * (m - j - 2) - 1) + (k & 1);
+}
+template <int MM>
+__device__ __forceinline__ void wave_bwd_transpose(int m, int n, int lane, const double* __restrict__ imd, WBwdPre<MM>& p) {
+  const bool colv = lane < n;
+  // one address per lane, compile-time offsets from it (pairs of reads merge into ds_read2_b64): entries that do not
+  // exist (row <= column, row >= m, lane >= n) are read from wherever that lands inside the staging area -- never
+  // below it: the smallest offset used is base + 2 >= 0 -- and replaced by zero
+  const double* q = imd + (colv ? wf_col_base(lane, m) : 0);
+#pragma unroll
+  for (int i4 = 0; i4 < MM / 2; i4 += 4) {
+    if (i4 < 12 || 2 * i4 < m) {          // (uniform; the recurrence skips the same groups of rows)
+#pragma unroll
+      for (int i = i4; i < i4 + 4; ++i) {
+        const bool ok0 = colv & (2 * i > lane) & (2 * i < m), ok1 = colv & (2 * i + 1 > lane) & (2 * i + 1 < m);
+        const double d0 = (i == 0) ? 0.0 : q[4 * i];          // (row 0 is above every column's diagonal)
+        const double d1 = q[4 * i + 2];
+        p.up[i].x = ok0 ? d0 : 0.0;
+        p.up[i].y = ok1 ? d1 : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int i = i4; i < i4 + 4; ++i) p.up[i] = double2_t{0.0, 0.0};
+    }
+  }
+}
+// the general (wide / part-solve) form: the forward image as a flat stream into the wave's LDS area `im` (any size up to
+// a 64 x 64 front's 16 KB; the launch sizes the area), its transpose out of it
 template <int MM, bool FAST>
-__device__ __forceinline__ void wave_bwd_load(const WTask& t, int lane, WBwdPre<MM>& p, const double* __restrict__ Lb,
+__device__ __forceinline__ void wave_bwd_load(const WTask& t, int lane, WBwdPre<MM>& p, const double* __restrict__ Lf,
+                                              double2_t* __restrict__ im,
                                               const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
                                               const int32_t* __restrict__ cmap, const int32_t* __restrict__ rlist,
                                               const double* __restrict__ xp, const double* __restrict__ slotv,
                                               const double* __restrict__ cvec, bool want_var) {
   const int m = t.m, n = t.n;
-  const int nrp = (m + 1) >> 1;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<double*>(Lb + t.lboff), 0, 16 * wb_pair_off(nrp, n), 0x00020000);
-  const int oob = int(0x80000000);
-  const int v0 = (lane < n) ? lane * 16 : oob;
+  {
+    const int nbytes = wf_image_bytes(m, n);
+    const __amdgpu_buffer_rsrc_t rs = wave_rsrc(Lf + t.lfoff, nbytes);
+    for (int c0 = 0; c0 * 1024 < nbytes; c0 += 4) {        // (uniform) four 1 KB pieces in flight at a time
+      double2_t ch[4];
 #pragma unroll
-  for (int i = 0; i < MM / 2; ++i) {
-    const bool ok = (lane <= 2 * i) & (2 * i < m);
-    p.up[i] = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? v0 : oob, wb_pair_off(i, n) * 16, 0));
+      for (int c = 0; c < 4; ++c) ch[c] = wave_ld_f64x2(rs, lane * 16, (c0 + c) * 1024);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if ((c0 + c) * 1024 < nbytes) im[(c0 + c) * 64 + lane] = ch[c];
+    }
+    wave_bwd_transpose<MM>(m, n, lane, reinterpret_cast<const double*>(im), p);
   }
   const int64_t s = int64_t(t.sptr) + lane;
   if (FAST) {
@@ -3171,14 +3232,14 @@ struct WBwdFlat {
   double xs, z;
   int gp, gv, pr;
 };
-__device__ __forceinline__ void wave_bwd_issue(const WTask& t, int lane, WBwdFlat& q, const double* __restrict__ Lb,
+__device__ __forceinline__ void wave_bwd_issue(const WTask& t, int lane, WBwdFlat& q, const double* __restrict__ Lf,
                                                const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
                                                const int32_t* __restrict__ cmap, const double* __restrict__ slotv,
                                                const double* __restrict__ cvec) {
   const int m = t.m, n = t.n;
-  const int nbytes = 16 * wb_pair_off((m + 1) >> 1, n);
+  const int nbytes = wf_image_bytes(m, n);
   const int oob = int(0x80000000);
-  const __amdgpu_buffer_rsrc_t rs = wave_rsrc(Lb + t.lboff, nbytes);
+  const __amdgpu_buffer_rsrc_t rs = wave_rsrc(Lf + t.lfoff, nbytes);
 #pragma unroll
   for (int c = 0; c < WIMG_CHUNKS; ++c) {
     q.ch[c] = double2_t{0.0, 0.0};
@@ -3194,25 +3255,12 @@ __device__ __forceinline__ void wave_bwd_issue(const WTask& t, int lane, WBwdFla
 __device__ __forceinline__ void wave_bwd_arrive(const WTask& t, int lane, const WBwdFlat& q, WBwdPre<40>& p,
                                                 double2_t* __restrict__ im) {
   const int m = t.m, n = t.n;
-  const int nbytes = 16 * wb_pair_off((m + 1) >> 1, n);
+  const int nbytes = wf_image_bytes(m, n);
 #pragma unroll
   for (int c = 0; c < WIMG_CHUNKS; ++c)
     if (c < 2 || c * 1024 < nbytes) im[c * 64 + lane] = q.ch[c];
   const bool colv = lane < n;
-#pragma unroll
-  for (int i4 = 0; i4 < 20; i4 += 4) {
-    if (i4 < 12 || 2 * i4 < m) {          // (uniform; the recurrence skips the same groups of rows)
-#pragma unroll
-      for (int i = i4; i < i4 + 4; ++i) {
-        const bool ok = colv & (lane <= 2 * i) & (2 * i < m);
-        const double2_t v = im[ok ? wb_pair_off(i, n) + lane : 0];
-        p.up[i] = ok ? v : double2_t{0.0, 0.0};
-      }
-    } else {
-#pragma unroll
-      for (int i = i4; i < i4 + 4; ++i) p.up[i] = double2_t{0.0, 0.0};
-    }
-  }
+  wave_bwd_transpose<40>(m, n, lane, reinterpret_cast<const double*>(im), p);
   p.pos = q.gp;
   p.var = q.gv;
   p.prow = q.pr;
@@ -3223,7 +3271,8 @@ template <int MM, bool PULLS, int AS = 64>
 __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const WBwdPre<MM>& p, double* __restrict__ xfull,
                                                  const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
                                                  double* __restrict__ xp, double* __restrict__ xout,
-                                                 const double* __restrict__ scale, double* __restrict__ cvec) {
+                                                 const double* __restrict__ scale, double* __restrict__ cvec,
+                                                 int2_t pull = int2_t{-1, -1}) {
   const int m = t.m, n = t.n;
   double x = p.x;
   {
@@ -3247,7 +3296,15 @@ __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const
   // children address the front by analyse-time rows (cmap, gather lists)
   const int arow = (lane < n) ? p.pos - t.sptr : lane;
   if ((t.flags & WT_INT) && (AS == 64 || lane < m)) xfull[t.myslot * AS + arow] = x;       // for the children inside the group
-  if (PULLS && (t.flags & WT_PULL)) {                          // ... and for those of earlier stages
+  if (PULLS && (t.flags & WT_PULL) && (t.flags & WT_DENSE)) {
+    // the dense table is by analyse-time ROW (= lane in the load): the value of row r sits in the lane whose pivot
+    // slot holds that row -- hand it over (a permutation of the pivot lanes; the other lanes keep theirs)
+    const int lo = __builtin_amdgcn_ds_permute(arow * 4, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_permute(arow * 4, __double2hiint(x));
+    const double xr = __hiloint2double(hi, lo);
+    if (pull.x >= 0) cvec[pull.x] = xr;
+    if (pull.y >= 0) cvec[pull.y] = xr;
+  } else if (PULLS && (t.flags & WT_PULL)) {                   // ... and for those of earlier stages
     const int lr = min(arow, m - 1);
     const int g0 = gth_ptr[t.goff + lr], g1 = (lane < m) ? gth_ptr[t.goff + lr + 1] : g0;
     const int last = max(g1 - 1, g0);
@@ -3279,7 +3336,7 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
              const double* __restrict__ Lf, const double* __restrict__ D, const int32_t* __restrict__ gperm,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, double* __restrict__ slotv,
-             double* __restrict__ cvec, Cols cs) {
+             double* __restrict__ cvec, Cols cs, const int32_t* __restrict__ pull2, int unit_tbeg) {
   constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
   __shared__ double accs[4][WSLOT * AS + 64];     // + a spare row (64 wide) for the masked lanes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3292,7 +3349,9 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
   double* acc = accs[wave];
 #pragma unroll
   for (int i = 0; i < WSLOT * AS + 64; i += 64) acc[i + lane] = 0.0;
-  const WGroup g = groups[gi];
+  // unit_tbeg >= 0: every run of this launch is ONE front, run gi = task unit_tbeg + gi -- no group record to fetch
+  // (a stage of the upper tree is a chain of dependent round trips: this is one of them)
+  const WGroup g = (unit_tbeg >= 0) ? WGroup{unit_tbeg + gi, 1} : groups[gi];
   const int te = g.tbeg + g.tcnt;
   if constexpr (NARROW) {
     // One register set: under load a round trip to HBM takes several times longer than a front's arithmetic, so a
@@ -3346,14 +3405,15 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
   } else {
     for (int ti = g.tbeg; ti < te; ++ti) {
       const WTask t = wave_task(tasks, ti);
+      const int2_t pull = wave_pull2_issue(t, lane, pull2);
       if (t.n <= 32) {
         WFwdPre<32> P;
         wave_fwd_load<32, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
-        wave_fwd_compute<32, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+        wave_fwd_compute<32, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec, pull);
       } else {
         WFwdPre<64> P;
         wave_fwd_load<64, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
-        wave_fwd_compute<64, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+        wave_fwd_compute<64, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec, pull);
       }
     }
   }
@@ -3366,9 +3426,11 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
              const double* __restrict__ Lb, const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ rlist, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, const double* __restrict__ slotv,
-             double* __restrict__ xout, const double* __restrict__ scale, double* __restrict__ cvec, Cols cs) {
+             double* __restrict__ xout, const double* __restrict__ scale, double* __restrict__ cvec, Cols cs,
+             const int32_t* __restrict__ pull2, int unit_tbeg, int wimg_units) {
   constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
   __shared__ double xfs[4][WSLOT * AS + 64];
+  extern __shared__ __attribute__((aligned(16))) double2_t wdyn[];    // wide launches: wimg_units 16-byte units per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GSLS_COLS;
   xp += col_ * cs.sx;
@@ -3378,7 +3440,7 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
   const int gi = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
   if (gi >= ngroup) return;
   double* xfull = xfs[wave];
-  const WGroup g = groups[gi];
+  const WGroup g = (unit_tbeg >= 0) ? WGroup{unit_tbeg + gi, 1} : groups[gi];
   const bool wv = xout != nullptr;
   if constexpr (NARROW) {
     int ti = g.tbeg + g.tcnt - 1;
@@ -3392,7 +3454,7 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
         wave_bwd_issue(ta, lane, Q, Lb, gperm, gvar, cmap, slotv, cvec);
         wave_bwd_arrive(ta, lane, Q, A, wimg[wave]);
       } else {
-        wave_bwd_load<40, true>(ta, lane, A, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+        wave_bwd_load<40, true>(ta, lane, A, Lb, wdyn + wave * wimg_units, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
       }
       wave_bwd_compute<40, false, AS>(ta, lane, A, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
       if (--ti < g.tbeg) break;
@@ -3401,14 +3463,15 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
   } else {
     for (int ti = g.tbeg + g.tcnt - 1; ti >= g.tbeg; --ti) {
       const WTask t = wave_task(tasks, ti);
+      const int2_t pull = wave_pull2_issue(t, lane, pull2);
       if (t.m <= 32) {
         WBwdPre<32> P;
-        wave_bwd_load<32, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
-        wave_bwd_compute<32, true>(t, lane, P, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+        wave_bwd_load<32, false>(t, lane, P, Lb, wdyn + wave * wimg_units, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+        wave_bwd_compute<32, true>(t, lane, P, xfull, gth_ptr, gth_src, xp, xout, scale, cvec, pull);
       } else {
         WBwdPre<64> P;
-        wave_bwd_load<64, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
-        wave_bwd_compute<64, true>(t, lane, P, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+        wave_bwd_load<64, false>(t, lane, P, Lb, wdyn + wave * wimg_units, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+        wave_bwd_compute<64, true>(t, lane, P, xfull, gth_ptr, gth_src, xp, xout, scale, cvec, pull);
       }
     }
   }
@@ -3440,8 +3503,9 @@ k_wsolve_tail(WTail tl, const WGroup* __restrict__ groups, const WTask* __restri
               const int32_t* __restrict__ rlist, const int32_t* __restrict__ gth_ptr, const int64_t* __restrict__ gth_src,
               double* __restrict__ xp, double* __restrict__ slotv, double* __restrict__ xout,
               const double* __restrict__ scale, double* __restrict__ cvec, Cols cs, int do_fwd, int do_bwd,
-              double* __restrict__ sink) {
+              double* __restrict__ sink, const int32_t* __restrict__ pull2, int wimg_units) {
   __shared__ double accs[WTAIL_WAVES][(WSLOT + 1) * 64];
+  extern __shared__ __attribute__((aligned(16))) double2_t wdyn[];    // wimg_units 16-byte units per wave (backward half)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col_ = blockIdx.x;
   xp += col_ * cs.sx;
@@ -3449,6 +3513,15 @@ k_wsolve_tail(WTail tl, const WGroup* __restrict__ groups, const WTask* __restri
   if (slotv) slotv += col_ * cs.sxs;
   if (xout) xout += col_ * cs.sio;
   double* acc = accs[wave];
+#ifdef GSLS_STAMPS     // wave 0's timeline (100 MHz ticks) into g_stamps[0..]: tools/stamp_tail.py
+  int stk = 0;
+#define TSTAMP() do { if (wave == 0 && lane == 0 && blockIdx.x == 0 && stk < 62) g_stamps[stk++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TSTAMPW() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); TSTAMP(); } while (0)
+#else
+#define TSTAMP() do {} while (0)
+#define TSTAMPW() do {} while (0)
+#endif
+  TSTAMP();
 #pragma unroll
   for (int i = 0; i <= WSLOT; ++i) acc[i * 64 + lane] = 0.0;
   {
@@ -3458,29 +3531,48 @@ k_wsolve_tail(WTail tl, const WGroup* __restrict__ groups, const WTask* __restri
     const double* tk = reinterpret_cast<const double*>(tasks + tl.tbeg);
     for (int64_t i = int64_t(tid) * 8; i < int64_t(tl.tcnt) * 8; i += int64_t(nt) * 8) warm += tk[i];
     if (do_fwd) for (int64_t i = tl.lf0 + int64_t(tid) * 8; i < tl.lf1; i += int64_t(nt) * 8) warm += Lf[i];
-    if (do_bwd) for (int64_t i = tl.lb0 + int64_t(tid) * 8; i < tl.lb1; i += int64_t(nt) * 8) warm += Lb[i];
+    if (do_bwd && !do_fwd) for (int64_t i = tl.lf0 + int64_t(tid) * 8; i < tl.lf1; i += int64_t(nt) * 8) warm += Lf[i];
     for (int64_t i = tl.gp0 + int64_t(tid) * 16; i < tl.gp1; i += int64_t(nt) * 16) warm += double(gth_ptr[i]);
     for (int64_t i = tl.gs0 + int64_t(tid) * 8; i < tl.gs1; i += int64_t(nt) * 8) warm += double(gth_src[i]);
+    // ... and the small vectors each front reads beside its image (right-hand side, D, maps, dense pull pairs): measured
+    // (tools/stamp_tail.py) a front's load phase waits 1.1 - 1.5 us for exactly these when only the images are warm
+    for (int ti = wave; ti < tl.tcnt; ti += WTAIL_WAVES) {
+      const WTask t = wave_task(tasks, tl.tbeg + ti);
+      const int64_t sl = int64_t(t.sptr) + lane;
+      if (lane < t.n) warm += xp[sl] + D[2 * sl] + double(gperm[sl]) + double(gvar[sl]);
+      if (lane < t.m - t.n) warm += double(cmap[t.moff + lane]) + cvec[t.moff + lane];
+      if ((t.flags & WT_DENSE) && lane < t.m) {
+        const int a = pull2[2 * (t.goff + lane)], b = pull2[2 * (t.goff + lane) + 1];
+        warm += cvec[max(a, 0)] + cvec[max(b, 0)];
+      }
+    }
     if (warm == 1.2345e-300) sink[0] = warm;      // (never: keeps the loads)
   }
+  TSTAMPW();
   if (do_fwd)
     for (int sg = 0; sg < tl.nst; ++sg) {
       for (int gi = wave; gi < tl.gcnt[sg]; gi += WTAIL_WAVES) {
         const WGroup g = groups[__builtin_amdgcn_readfirstlane(tl.gbeg[sg] + gi)];
         for (int ti = g.tbeg; ti < g.tbeg + g.tcnt; ++ti) {
           const WTask t = wave_task(tasks, ti);
+          TSTAMPW();                        // group + task records
+          const int2_t pull = wave_pull2_issue(t, lane, pull2);
           if (t.n <= 32) {
             WFwdPre<32> P;
             wave_fwd_load<32, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
-            wave_fwd_compute<32, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+            TSTAMPW();                      // loads
+            wave_fwd_compute<32, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec, pull);
           } else {
             WFwdPre<64> P;
             wave_fwd_load<64, APPLY_D>(t, lane, P, Lf, D, gperm, cmap, xp);
-            wave_fwd_compute<64, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec);
+            TSTAMPW();                      // loads
+            wave_fwd_compute<64, APPLY_D, true>(t, lane, P, acc, gth_ptr, gth_src, xp, slotv, cvec, pull);
           }
+          TSTAMPW();                        // pulls, recurrence, stores
         }
       }
       __syncthreads();
+      TSTAMP();                             // barrier
     }
   if (do_bwd) {
     const bool wv = xout != nullptr;
@@ -3489,14 +3581,15 @@ k_wsolve_tail(WTail tl, const WGroup* __restrict__ groups, const WTask* __restri
         const WGroup g = groups[__builtin_amdgcn_readfirstlane(tl.gbeg[sg] + gi)];
         for (int ti = g.tbeg + g.tcnt - 1; ti >= g.tbeg; --ti) {
           const WTask t = wave_task(tasks, ti);
+          const int2_t pull = wave_pull2_issue(t, lane, pull2);
           if (t.m <= 32) {
             WBwdPre<32> P;
-            wave_bwd_load<32, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
-            wave_bwd_compute<32, true>(t, lane, P, acc, gth_ptr, gth_src, xp, xout, scale, cvec);
+            wave_bwd_load<32, false>(t, lane, P, Lf, wdyn + wave * wimg_units, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+            wave_bwd_compute<32, true>(t, lane, P, acc, gth_ptr, gth_src, xp, xout, scale, cvec, pull);
           } else {
             WBwdPre<64> P;
-            wave_bwd_load<64, false>(t, lane, P, Lb, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
-            wave_bwd_compute<64, true>(t, lane, P, acc, gth_ptr, gth_src, xp, xout, scale, cvec);
+            wave_bwd_load<64, false>(t, lane, P, Lf, wdyn + wave * wimg_units, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
+            wave_bwd_compute<64, true>(t, lane, P, acc, gth_ptr, gth_src, xp, xout, scale, cvec, pull);
           }
         }
       }
@@ -3529,14 +3622,12 @@ k_wpack(const WTask* __restrict__ tasks, const WPack* __restrict__ packs, int nt
   const int ld = (m + 1) & ~1;
   const double* A = L + pk.loff;
   double* f = Lf + t.lfoff;
-  double* bk = Lb + t.lboff;
   const int r = lane;
   if (r >= m) return;
   for (int k = 0; k < n && k < r; ++k) {
     const double v = A[int64_t(k) * ld + r];
     const int j = k >> 1;
     f[2 * (wf_pair_off(j, m) + r - (2 * j + 1)) + (k & 1)] = v;
-    bk[2 * (wb_pair_off(r >> 1, n) + k) + (r & 1)] = v;
   }
 }
 
@@ -3586,7 +3677,6 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
   };
   const bool images = Lf && t.lfoff >= 0;
   double* fimg = Lf + (images ? t.lfoff : 0);
-  double* bimg = Lbk + (images ? t.lboff : 0);
   double* Lb = L + t.loff;
   int w = 0;
   for (int c0 = 0; c0 < n; c0 += w) {
@@ -3665,7 +3755,6 @@ k_front_blk(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherList
           if (in && lane > k) {
             const int j2 = k >> 1;
             fimg[2 * (wf_pair_off(j2, m) + lane - (2 * j2 + 1)) + (k & 1)] = a[q];
-            bimg[2 * (wb_pair_off(lane >> 1, n) + k) + (lane & 1)] = a[q];
           }
         } else if (in && lane >= k) {
           Lb[int64_t(k) * t.ld + lane] = a[q];
@@ -3873,7 +3962,7 @@ void dev_free(DeviceFactor& F) {
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec, F.xp_mr, F.cvec_mr,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
-                  F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
+                  F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wpull2, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : {static_cast<void*>(F.mc_xp), static_cast<void*>(F.mc_xs), static_cast<void*>(F.mc_cvec),
@@ -3913,6 +4002,11 @@ static hipError_t allow_big_lds() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_chol), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  // the wide backward launches of the wave tier stage one forward image per wave (up to 16 KB) beside their static LDS
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_bwd<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_bwd<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   return hipSuccess;
 }
 
@@ -3944,13 +4038,16 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   const int64_t nz = S.nptr[nn];
   std::vector<int64_t> asrc(nz), adst(nz);
   std::vector<int32_t> arow(nz), acol(nz), aloc(nz);
+  // (a sharded run lays out only the fronts this rank owns, shard_layout: the others' entries are not scattered)
+  const bool rank_layout = !S.owner.empty() && S.nranks > 1 && int(S.czptr.size()) == 2 * S.nlevels + 1;
   for (int s = 0; s < nn; ++s) {
     const int64_t m = S.nrow(s);
+    const bool here = !rank_layout || S.owner[s] == F.myrank || (S.owner[s] < 0 && F.myrank == 0);
     for (int64_t k = S.nptr[s]; k < S.nptr[s + 1]; ++k) {
       const int64_t dst = S.nlist[2 * k + 1];
       const int64_t c = dst / m, r = dst % m;
       asrc[k] = S.nlist[2 * k];
-      adst[k] = S.loff[s] + c * S.ldl[s] + r;
+      adst[k] = here ? S.loff[s] + c * S.ldl[s] + r : -1;
       aloc[k] = (m <= 64) ? int32_t(c * m - c * (c + 1) / 2 + r) : 0;     // k_front_wave's packed triangle in LDS
       arow[k] = S.rlist[S.rptr[s] + r];
       acol[k] = S.sptr[s] + int(c);
@@ -4290,6 +4387,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       std::vector<WPack> wp(nT);
       std::vector<int32_t> gptr(1, 0);
       std::vector<int64_t> gsrc;
+      std::vector<int32_t> pull2;
       {
         std::vector<int64_t> fill(gtbeg);
         for (int s = 0; s < nn; ++s) {        // ascending node number = postorder inside every group
@@ -4324,7 +4422,6 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         of += wf_size(t.m, t.n);
         ob += wb_size(t.m, t.n);
         if (!(t.flags & WT_PULL)) continue;
-        t.goff = int64_t(gptr.size()) - 1;
         std::vector<std::vector<int64_t>> rows(pm);
         for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
           const int c = S.clist[ci];
@@ -4332,6 +4429,19 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
           const int ccm = S.nrow(c) - S.ncol(c);
           for (int k = 0; k < ccm; ++k) rows[S.cmap[S.cmapptr[c] + k]].push_back(S.cmapptr[c] + k);
         }
+        {
+          // at most two sources per row and 32-bit indices: the dense form (one 8-byte pair per row)
+          size_t longest = 0;
+          for (int r2 = 0; r2 < pm; ++r2) longest = std::max(longest, rows[r2].size());
+          if (longest <= 2 && int64_t(S.cmapptr[nn]) < (int64_t(1) << 31) && !getenv("GSLS_NO_WPULL2")) {
+            t.flags |= WT_DENSE;
+            t.goff = int64_t(pull2.size() / 2);
+            for (int r2 = 0; r2 < pm; ++r2)
+              for (size_t q = 0; q < 2; ++q) pull2.push_back(q < rows[r2].size() ? int32_t(rows[r2][q]) : -1);
+            continue;
+          }
+        }
+        t.goff = int64_t(gptr.size()) - 1;
         for (int r2 = 0; r2 < pm; ++r2) {
           gsrc.insert(gsrc.end(), rows[r2].begin(), rows[r2].end());
           gptr.push_back(int32_t(gsrc.size()));
@@ -4349,6 +4459,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
               maxm = std::max(maxm, int(wt[ti].m));
               if (wt[ti].flags & WT_PULL) {
                 ++npull;
+                if (wt[ti].flags & WT_DENSE) { maxsrc = std::max(maxsrc, 2); continue; }
                 for (int r2 = 0; r2 < wt[ti].m; ++r2)
                   maxsrc = std::max(maxsrc, int(gptr[wt[ti].goff + r2 + 1] - gptr[wt[ti].goff + r2]));
               }
@@ -4361,12 +4472,17 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         tk.lfoff = nlf[tk.node];
         tk.lboff = nlb[tk.node];
       }
+      {
+        int64_t big = 0;      // the wide launches stage one image per wave in LDS: whole 1 KB pieces
+        for (int64_t ti = 0; ti < nT; ++ti) big = std::max<int64_t>(big, 8 * wf_size(wt[ti].m, wt[ti].n));
+        F.wimg_units = int(((big + 1023) / 1024) * 64);
+      }
       // the tail: the longest run of last stages with at most WTAIL_WAVES groups each (never stage 0)
       F.wtail_k0 = -1;
       if (!getenv("GSLS_NO_WTAIL")) {
         int k0 = nstage;
         while (k0 - 1 >= 1 && F.wstage_cnt[k0 - 1] <= WTAIL_WAVES && nstage - (k0 - 1) <= WTAIL_STAGES) --k0;
-        if (nstage - k0 >= 2) {               // (a single stage is a single launch either way)
+        if (nstage - k0 >= 2 && int64_t(WTAIL_WAVES) * F.wimg_units * 16 <= 116 * 1024) {   // (one stage = one launch either way)
           F.wtail_k0 = k0;
           F.wtail_tbeg = wg[F.wstage_begin[k0]].tbeg;
           F.wtail_tcnt = nT - F.wtail_tbeg;
@@ -4374,7 +4490,7 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
           F.wtail_lb0 = wt[F.wtail_tbeg].lboff;
           F.wtail_gp0 = F.wtail_gp1 = int64_t(gptr.size()) - 1;
           for (int64_t ti = F.wtail_tbeg; ti < nT; ++ti)
-            if (wt[ti].flags & WT_PULL) F.wtail_gp0 = std::min<int64_t>(F.wtail_gp0, wt[ti].goff);
+            if ((wt[ti].flags & WT_PULL) && !(wt[ti].flags & WT_DENSE)) F.wtail_gp0 = std::min<int64_t>(F.wtail_gp0, wt[ti].goff);
           F.wtail_gs0 = gptr[F.wtail_gp0];
           F.wtail_gs1 = int64_t(gsrc.size());
         }
@@ -4385,7 +4501,8 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       F.wnont_cnt = int(nont.size());
       F.wtask_cnt = nT;
       F.Lf_elems = of;
-      F.Lb_elems = ob;
+      F.Lb_elems = 0;
+
       {
         WTask* d1 = nullptr;
         WGroup* d2 = nullptr;
@@ -4400,11 +4517,20 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       gsrc.insert(gsrc.end(), 16, 0);            // (the pipelined gathers read one clamped index past a row's list)
       HIPCHK(upload(F.wgth_ptr, gptr, st));
       HIPCHK(upload(F.wgth_src, gsrc, st));
+      pull2.resize(pull2.size() + 128, -1);      // (the masked 8-byte loads never read it; keeps the buffer non-empty)
+      HIPCHK(upload(F.wpull2, pull2, st));
+      // stages whose runs are all single fronts (the upper tree): run gi = task tbeg + gi, no group record needed
+      F.wstage_unit.assign(nstage, -1);
+      for (int k = 0; k < nstage; ++k) {
+        bool unit = F.wstage_cnt[k] > 0;
+        for (int r = F.wstage_begin[k]; unit && r < F.wstage_begin[k] + F.wstage_cnt[k]; ++r)
+          unit = wg[r].tcnt == 1 && wg[r].tbeg == wg[F.wstage_begin[k]].tbeg + (r - F.wstage_begin[k]);
+        if (unit) F.wstage_unit[k] = wg[F.wstage_begin[k]].tbeg;
+      }
       HIPCHK(upload(F.wnont, nont, st));
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.Lf), std::max<int64_t>(of, 2) * sizeof(double)));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.Lb), std::max<int64_t>(ob, 2) * sizeof(double)));
+      F.Lb = nullptr;       // (one image since round 3: the backward sweep transposes Lf in LDS)
       HIPCHK(hipMemsetAsync(F.Lf, 0, std::max<int64_t>(of, 2) * sizeof(double), st));   // the diagonal slots stay 0
-      HIPCHK(hipMemsetAsync(F.Lb, 0, std::max<int64_t>(ob, 2) * sizeof(double), st));
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xs), (std::max(S.n, 1) + 64) * sizeof(double)));
       HIPCHK(hipMemsetAsync(F.xs, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gvar), (std::max(S.n, 1) + 64) * sizeof(int32_t)));
@@ -4560,10 +4686,11 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
   F.C_elems = S.coff[nn];
   {
     std::vector<ZeroTask> zt;
-    F.cz_begin.assign(S.nlevels, 0);
-    F.cz_cnt.assign(S.nlevels, 0);
+    const int nzl = std::max(int(S.czptr.size()) - 1, S.nlevels);   // (2 * nlevels with a per-rank layout: phase 2 behind phase 1)
+    F.cz_begin.assign(nzl, 0);
+    F.cz_cnt.assign(nzl, 0);
     const int64_t chunk = int64_t(1) << 13;        // 64 KB per workgroup
-    for (int l = 0; l < S.nlevels; ++l) {
+    for (int l = 0; l < int(S.czptr.size()) - 1; ++l) {
       F.cz_begin[l] = int(zt.size());
       for (int r = S.czptr[l]; r < S.czptr[l + 1]; ++r)
         for (int64_t o = 0; o < S.czlen[r]; o += chunk) zt.push_back(ZeroTask{S.czoff[r] + o, std::min(chunk, S.czlen[r] - o)});
@@ -4605,11 +4732,14 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
   const size_t lds_panel = std::max(sizeof(Stage<RB>), sizeof(double) * (NB * RBP + NB * NB));
   const size_t lds_chol = std::max(sizeof(Stage<PR, CK>), sizeof(double) * LDQ * NB);
   const size_t lds_pchol = std::max(sizeof(Stage<RB, CK>), sizeof(double) * (2 * NB * RBP));
+  // a sharded run with a per-rank layout keeps phase 2's clear lists behind phase 1's (shard_layout)
+  const int zbase = (which == 2 && int(F.cz_cnt.size()) == 2 * S.nlevels) ? S.nlevels : 0;
+  if (zbase > 0) zero_c = true;
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
-    if (zero_c && F.cz_cnt[l] > 0)     // the contribution blocks this level's fronts own (arena space is reused)
-      hipLaunchKernelGGL(k_zero_tasks, dim3(F.cz_cnt[l]), dim3(256), 0, st,
-                         static_cast<const ZeroTask*>(F.cztasks) + F.cz_begin[l], F.C);
+    if (zero_c && F.cz_cnt[zbase + l] > 0)     // the contribution blocks this level's fronts own (arena space is reused)
+      hipLaunchKernelGGL(k_zero_tasks, dim3(F.cz_cnt[zbase + l]), dim3(256), 0, st,
+                         static_cast<const ZeroTask*>(F.cztasks) + F.cz_begin[zbase + l], F.C);
     if (lp.pull_cnt > 0)
       hipLaunchKernelGGL(k_assemble_pull, dim3(lp.pull_cnt), dim3(256), 0, st,
                          static_cast<const PullTask*>(F.pulltasks) + lp.pull_begin,
@@ -5042,26 +5172,27 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   // (experiment knob: unused dynamic LDS per workgroup of the narrow wave kernels = fewer waves per CU)
   static const size_t ws_pad = getenv("GSLS_WS_LDSPAD") ? size_t(atoi(getenv("GSLS_WS_LDSPAD"))) : 0;
   static const bool ws_flat = !(getenv("GSLS_WS_FLAT") && atoi(getenv("GSLS_WS_FLAT")) == 0);   // (A/B knob)
-  auto wave_fwd = [&](int g0, int cnt, bool narrow) {
+  auto wave_fwd = [&](int g0, int cnt, bool narrow, int unit = -1) {
     if (cnt <= 0) return;
 #define GSLS_WFWD(D_, N_, F_)                                                                                      \
   hipLaunchKernelGGL((k_wsolve_fwd<D_, N_, F_>), dim3(((cnt + 3) / 4) * R), dim3(256), (N_) ? ws_pad : 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
-                     F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cs)
+                     F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cs, F.wpull2, unit)
     if (fuse_d) { if (narrow) { if (ws_flat) GSLS_WFWD(true, true, true); else GSLS_WFWD(true, true, false); } else GSLS_WFWD(true, false, false); }
     else { if (narrow) { if (ws_flat) GSLS_WFWD(false, true, true); else GSLS_WFWD(false, true, false); } else GSLS_WFWD(false, false, false); }
 #undef GSLS_WFWD
   };
-  auto wave_bwd = [&](int g0, int cnt, bool narrow) {
+  auto wave_bwd = [&](int g0, int cnt, bool narrow, int unit = -1) {
     if (cnt <= 0) return;
+    const int wu = F.wimg_units;      // LDS staging area per wave of the wide launches (16-byte units)
     if (narrow && ws_flat)
-      hipLaunchKernelGGL((k_wsolve_bwd<true, true>), dim3(((cnt + 3) / 4) * R), dim3(256), ws_pad, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
-                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs);
+      hipLaunchKernelGGL((k_wsolve_bwd<true, true>), dim3(((cnt + 3) / 4) * R), dim3(256), ws_pad, st, wgr + g0, cnt, wtk, F.Lf, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, F.wpull2, unit, wu);
     else if (narrow)
-      hipLaunchKernelGGL(k_wsolve_bwd<true>, dim3(((cnt + 3) / 4) * R), dim3(256), ws_pad, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
-                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs);
+      hipLaunchKernelGGL(k_wsolve_bwd<true>, dim3(((cnt + 3) / 4) * R), dim3(256), ws_pad + size_t(4) * wu * 16, st, wgr + g0, cnt, wtk, F.Lf, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, F.wpull2, unit, wu);
     else
-      hipLaunchKernelGGL(k_wsolve_bwd<false>, dim3(((cnt + 3) / 4) * R), dim3(256), 0, st, wgr + g0, cnt, wtk, F.Lb, F.gperm,
-                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs);
+      hipLaunchKernelGGL(k_wsolve_bwd<false>, dim3(((cnt + 3) / 4) * R), dim3(256), size_t(4) * wu * 16, st, wgr + g0, cnt, wtk, F.Lf, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, F.wpull2, unit, wu);
   };
   if (ev) HIPCHK(hipEventRecord(ev[0], st));
   const bool ahead = slotv != nullptr && scale == nullptr;  // the look-ahead kernels: job ALL, no user scaling
@@ -5079,21 +5210,21 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
     tl.tbeg = F.wtail_tbeg;
     tl.tcnt = F.wtail_tcnt;
     tl.lf0 = F.wtail_lf0; tl.lf1 = F.Lf_elems;
-    tl.lb0 = F.wtail_lb0; tl.lb1 = F.Lb_elems;
+    tl.lb0 = 0; tl.lb1 = 0;
     tl.gp0 = F.wtail_gp0; tl.gp1 = F.wtail_gp1;
     tl.gs0 = F.wtail_gs0; tl.gs1 = F.wtail_gs1;
     if (fuse_d && df)
-      hipLaunchKernelGGL(k_wsolve_tail<true>, dim3(R), dim3(64 * WTAIL_WAVES), 0, st, tl, wgr, wtk, F.Lf, F.Lb, F.D, F.gperm,
-                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, df, db, F.D);
+      hipLaunchKernelGGL(k_wsolve_tail<true>, dim3(R), dim3(64 * WTAIL_WAVES), size_t(WTAIL_WAVES) * F.wimg_units * 16, st, tl, wgr, wtk, F.Lf, F.Lf, F.D, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, df, db, F.D, F.wpull2, F.wimg_units);
     else
-      hipLaunchKernelGGL(k_wsolve_tail<false>, dim3(R), dim3(64 * WTAIL_WAVES), 0, st, tl, wgr, wtk, F.Lf, F.Lb, F.D, F.gperm,
-                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, df, db, F.D);
+      hipLaunchKernelGGL(k_wsolve_tail<false>, dim3(R), dim3(64 * WTAIL_WAVES), size_t(WTAIL_WAVES) * F.wimg_units * 16, st, tl, wgr, wtk, F.Lf, F.Lf, F.D, F.gperm,
+                         F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, df, db, F.D, F.wpull2, F.wimg_units);
   };
   if (do_fwd && wave) {
     for (int k = 0; k < ktail; ++k) {                       // stages of small subtrees, bottom-up
       const int nar = ahead ? F.wstage_narrow[k] : 0;
       wave_fwd(F.wstage_begin[k], nar, true);
-      wave_fwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false);
+      wave_fwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false, nar == 0 ? F.wstage_unit[k] : -1);
     }
     if (ktail < nstage) wave_tail(1, tail_both ? 1 : 0);
   }
@@ -5188,7 +5319,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   if (do_bwd && wave)
     for (int k = ktail - 1; k >= 0; --k) {
       const int nar = ahead ? F.wstage_narrow[k] : 0;
-      wave_bwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false);
+      wave_bwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false, nar == 0 ? F.wstage_unit[k] : -1);
       wave_bwd(F.wstage_begin[k], nar, true);
     }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));

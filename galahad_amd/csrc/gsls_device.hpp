@@ -151,6 +151,9 @@ struct DeviceFactor {
   // tasks and the element ranges of their images / gather lists
   int wtail_k0 = -1, wtail_tbeg = 0, wtail_tcnt = 0;
   int64_t wtail_lf0 = 0, wtail_lb0 = 0, wtail_gp0 = 0, wtail_gp1 = 0, wtail_gs0 = 0, wtail_gs1 = 0;
+  int wimg_units = 64;            // LDS staging area per wave of the wide backward launches (16-byte units)
+  int32_t* wpull2 = nullptr;      // dense form of the gather lists for fronts with at most two sources per row
+  std::vector<int> wstage_unit;   // per stage: first task if every run is one front in task order, else -1
   int32_t* wgth_ptr = nullptr;    // gather lists of the covered fronts (rows -> children's contribution entries)
   int64_t* wgth_src = nullptr;
   int32_t* wnont = nullptr;       // fronts the tier does not cover (for the D solve)
