@@ -70,6 +70,7 @@ SIGNATURES = {
     "gsls_shard_failed": (C.c_int, [C.c_void_p, C.POINTER(i32), p_i32]),
     "gsls_shard_repair": (C.c_int, [C.c_void_p, i32, p_i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gsls_shard_get": (C.c_int, [C.c_void_p, p_i32, C.POINTER(i32), p_i32]),
+    "gsls_get_layout_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gsls_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gsls_comm_init": (C.c_int, [C.c_void_p, i32, i32, C.c_char_p, C.POINTER(Options)]),
     "gsls_comm_factor_dev": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.POINTER(Options), C.POINTER(Inform)]),

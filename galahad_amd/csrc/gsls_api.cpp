@@ -1233,6 +1233,7 @@ int gsls_shard(void* handle, int32_t nranks, int32_t rank, int64_t* xchg_factor_
   if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
   if (nranks < 1 || rank < 0 || rank >= nranks) return GSLS_ERROR_CALL_SEQUENCE;
   shard_tree(h->S, nranks);
+  if (nranks > 1 && !getenv("GSLS_SHARD_FULL_LAYOUT")) shard_layout(h->S, rank);   // this rank's fronts and blocks only
   h->F.myrank = rank;
   h->dev_ready = false;   // plans are rebuilt on the next factorization
   h->factored = false;
@@ -1746,6 +1747,17 @@ int gsls_comm_init_env(void* handle, const gsls_options* options) {
   }
   const int f = gsls_comm_init(handle, nranks, rank, id, options);
   return f < 0 ? f : 1;
+}
+
+// what this handle allocates on its device for the factors and for the contribution-block arena, in doubles: the
+// whole tree on one device; after gsls_shard(nranks > 1) only the fronts and blocks of this rank (shard_layout)
+int gsls_get_layout_sizes(void* handle, int64_t* factor_elems, int64_t* arena_elems) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !h->analysed) return GSLS_ERROR_CALL_SEQUENCE;
+  const int nn = h->S.nnodes;
+  if (factor_elems) *factor_elems = nn ? h->S.loff[nn] : 0;
+  if (arena_elems) *arena_elems = nn ? h->S.coff[nn] : 0;
+  return GSLS_SUCCESS;
 }
 
 // owner rank of every supernode (-1: top part) and the cut roots, for callers that want to inspect

@@ -69,6 +69,7 @@ void order_nested_dissection(int n, const std::vector<int64_t>& aptr, const std:
 // work, everything above them (the top part) stays with rank 0 (cf. find_subtree_partition,
 // src/ssids/anal.f90:284-459).  Fills S.owner / S.cutroots.
 void shard_tree(Symbolic& S, int nranks);
+void shard_layout(Symbolic& S, int rank);    // per-rank factor / arena offsets (only what the rank owns)
 
 // offsets of the contribution blocks: reuse = true packs them by lifetime (single device), false lays them out one
 // after the other (multi-GPU: the cut roots' blocks must survive until the exchange)

@@ -579,6 +579,8 @@ void shard_tree(Symbolic& S, int nranks) {
   S.nranks = std::max(1, nranks);
   S.owner.assign(nn, 0);
   S.cutroots.clear();
+  for (int s = 0; s < nn; ++s)         // (a per-rank layout of an earlier sharding may be in place: shard_layout)
+    S.loff[s + 1] = S.loff[s] + int64_t(S.ldl[s]) * S.ncol(s);
   if (S.nranks > 1) layout_contrib(S, false);      // the cut roots' blocks outlive their level: no reuse across ranks
   else layout_contrib_auto(S);
   if (S.nranks <= 1 || nn == 0) return;
@@ -630,6 +632,112 @@ void shard_tree(Symbolic& S, int nranks) {
   std::sort(cut.begin(), cut.end());
   for (int c : cut)
     if (S.sparent[c] < nn) S.cutroots.push_back(c);   // roots of the whole tree send nothing
+}
+
+// Per-rank memory of a sharded run (round 3).  shard_tree leaves the single-device layout in place: every rank would
+// allocate ALL of L and a side-by-side arena for every front's contribution block -- O(total) per rank, > 500 GB of
+// arena for BASELINE configs[4] against 288 GB of HBM.  This lays out, for ONE rank, only what that rank touches:
+//   * factors: the fronts it owns (rank 0: and the top part); the others get length 0;
+//   * contribution blocks: two regions, each reused by lifetime exactly as layout_contrib does on one device, in the
+//     order the rank really runs its fronts --
+//       region 1: the fronts of its subtrees, level by level (phase 1).  A cut root's block is never released there
+//                 (its parent is in the top part): it is what the rank sends;
+//       region 2 (rank 0 only): first, pinned, the blocks of the OTHER ranks' cut roots (they arrive through the
+//                 exchange; a block is released when the top front that pulls it has run), then the top part's
+//                 own blocks level by level (phase 2).
+//     The ranges to clear before a level are kept per (phase, level): czptr has 2 * nlevels + 1 entries, phase 2's
+//     levels behind phase 1's; received blocks are never cleared.
+// Every front's offsets are only meaningful on the rank that owns it; the symbolic data proper (sptr, rlist, maps,
+// statistics) stays identical on all ranks.
+void shard_layout(Symbolic& S, int rank) {
+  const int nn = S.nnodes, L = S.nlevels;
+  if (S.nranks <= 1 || nn == 0 || int(S.owner.size()) != nn) return;
+  auto top = [&](int s) { return S.owner[s] < 0; };
+  auto mine = [&](int s) { return S.owner[s] == rank || (top(s) && rank == 0); };
+  auto clen = [&](int s) { const int64_t cm = S.nrow(s) - S.ncol(s); return cm * cm; };
+  S.loff.assign(nn + 1, 0);
+  for (int s = 0; s < nn; ++s)
+    S.loff[s + 1] = S.loff[s] + (mine(s) ? int64_t(S.ldl[s]) * S.ncol(s) : 0);
+  S.coff.assign(nn + 1, 0);
+  S.czptr.assign(2 * L + 1, 0);
+  S.czoff.clear();
+  S.czlen.clear();
+  std::vector<std::pair<int64_t, int64_t>> freel;     // (offset, length), sorted by offset, coalesced
+  int64_t topoff = 0;
+  auto alloc = [&](int64_t len) -> int64_t {
+    for (size_t i = 0; i < freel.size(); ++i)
+      if (freel[i].second >= len) {
+        const int64_t off = freel[i].first;
+        if (freel[i].second == len) freel.erase(freel.begin() + i);
+        else { freel[i].first += len; freel[i].second -= len; }
+        return off;
+      }
+    if (!freel.empty() && freel.back().first + freel.back().second == topoff) {
+      const int64_t off = freel.back().first;
+      topoff = off + len;
+      freel.pop_back();
+      return off;
+    }
+    const int64_t off = topoff;
+    topoff += len;
+    return off;
+  };
+  auto release = [&](int64_t off, int64_t len) {
+    auto it = std::lower_bound(freel.begin(), freel.end(), std::make_pair(off, int64_t(0)));
+    it = freel.insert(it, std::make_pair(off, len));
+    if (it + 1 != freel.end() && it->first + it->second == (it + 1)->first) {
+      it->second += (it + 1)->second;
+      freel.erase(it + 1);
+    }
+    if (it != freel.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+      (it - 1)->second += it->second;
+      freel.erase(it);
+    }
+  };
+  std::vector<std::pair<int64_t, int64_t>> zr;
+  auto run_phase = [&](int phase) {
+    for (int l = 0; l < L; ++l) {
+      const int v = (phase - 1) * L + l;
+      zr.clear();
+      for (int i = S.lvlptr[l]; i < S.lvlptr[l + 1]; ++i) {
+        const int s = S.lvlnodes[i];
+        if (!mine(s) || (phase == 1) == top(s)) continue;
+        const int64_t len = clen(s);
+        if (len == 0) continue;
+        S.coff[s] = alloc(len);
+        zr.emplace_back(S.coff[s], len);
+      }
+      std::sort(zr.begin(), zr.end());
+      for (size_t i = 0; i < zr.size(); ++i) {
+        if (!S.czoff.empty() && int(S.czoff.size()) > S.czptr[v] && S.czoff.back() + S.czlen.back() == zr[i].first)
+          S.czlen.back() += zr[i].second;
+        else {
+          S.czoff.push_back(zr[i].first);
+          S.czlen.push_back(zr[i].second);
+        }
+      }
+      S.czptr[v + 1] = int(S.czoff.size());
+      for (int i = S.lvlptr[l]; i < S.lvlptr[l + 1]; ++i) {
+        const int s = S.lvlnodes[i];
+        if (!mine(s) || (phase == 1) == top(s)) continue;
+        for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) {
+          const int c = S.clist[ci];
+          if (clen(c) > 0) release(S.coff[c], clen(c));     // (a top front's children include received cut roots)
+        }
+      }
+    }
+  };
+  run_phase(1);
+  // region 2 starts behind everything phase 1 ever used: this rank's own cut roots stay where phase 1 left them
+  freel.clear();
+  if (rank == 0) {
+    for (int c : S.cutroots)
+      if (S.owner[c] != 0 && clen(c) > 0) S.coff[c] = alloc(clen(c));      // pinned until their parent has run
+    run_phase(2);
+  } else {
+    for (int v = L; v < 2 * L; ++v) S.czptr[v + 1] = int(S.czoff.size());
+  }
+  S.coff[nn] = topoff;
 }
 
 }  // namespace gsls

@@ -241,6 +241,9 @@ int gsls_shard_repair(void* handle, int32_t nfailed, const int32_t* failed, int6
                       int64_t* xchg_solve_elems);
 /* the partition: owner[nnodes] (rank, -1 = top part), number of cut roots and their 1-based indices */
 int gsls_shard_get(void* handle, int32_t* owner, int32_t* ncut, int32_t* cutroots);
+/* device memory of this handle in doubles: the factors and the contribution-block arena.  One device: the whole tree;
+ * after gsls_shard with nranks > 1: this rank's fronts (rank 0: and the top part) and blocks only */
+int gsls_get_layout_sizes(void* handle, int64_t* factor_elems, int64_t* arena_elems);
 
 /* ---- multi-GPU with the exchange INSIDE the library (RCCL on the handle's stream) -----------------------------------
  * replaces what ssids_factor / ssids_solve do for several devices in one call (src/ssids/fkeep.F90:99-174, 229-318;
