@@ -336,7 +336,35 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
     } else {
       for (int64_t k = 0; k < ptr[n] - 1; ++k)
         if (row[k] < 1 || row[k] > n) return inform->flag = GSLS_ERROR_A_ALL_OOR;
-      flag = symbolic_analyse(n, ptr, row, order, options->ordering, options->nemin, h->S);
+      int nemin = options->nemin;
+      if (nemin <= 0) {
+        // nemin = 0: the backend chooses (what SLS_initialize('gsls') leaves in control%node_amalgamation).  A tree of
+        // tens of thousands of tiny fronts -- a KKT / banded-Hessian system with a couple of entries per column --
+        // runs a wave per front: 24 keeps them within one wavefront (n <= 32, m <= 64) and adds few explicit zeros (2x
+        // faster than 64 on the metric workload).  Everything else gets 64, the setting of rounds 1 and 2 (fewer,
+        // fatter fronts for the MFMA updates).  The cheap guess (entries per column) is checked on the tree it gives;
+        // if the factor does not sit in fronts of at most 64 rows after all, the analysis is repeated with 64.
+        const bool guess_tiny = double(ptr[n] - 1) <= 2.5 * double(n);
+        nemin = guess_tiny ? 24 : 64;
+        std::vector<int32_t> keep;
+        if (order) keep.assign(order, order + n);
+        flag = symbolic_analyse(n, ptr, row, order, options->ordering, nemin, h->S);
+        if (flag >= 0 && guess_tiny) {
+          int64_t small = 0, all = 0;
+          for (int sn = 0; sn < h->S.nnodes; ++sn) {
+            const int64_t e = int64_t(h->S.nrow(sn)) * h->S.ncol(sn);
+            all += e;
+            if (h->S.nrow(sn) <= 64) small += e;
+          }
+          if (small * 10 < all * 9) {
+            nemin = 64;
+            if (order) std::copy(keep.begin(), keep.end(), order);
+            flag = symbolic_analyse(n, ptr, row, order, options->ordering, nemin, h->S);
+          }
+        }
+      } else {
+        flag = symbolic_analyse(n, ptr, row, order, options->ordering, nemin, h->S);
+      }
       h->ptr.assign(ptr, ptr + n + 1);
       h->row.assign(row, row + (ptr[n] - 1));
       h->diagpos.assign(n, -1);
@@ -349,7 +377,7 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
       h->partner.assign(n, -1);
       h->tpp_unflagged = false;
       h->tpp_dirty = true;
-      h->nemin = options->nemin;
+      h->nemin = nemin;
       h->own_order = (options->ordering != GSLS_ORDER_USER);
       h->preordered = false;
     }

@@ -2901,6 +2901,9 @@ struct WFwdPre {
   int pslot, prow;
 };
 
+// (The wide forward launches -- upper stages, one front per wave, latency-bound -- keep this form: the flat stream
+//  through LDS that pays in the bottom stage was measured here too and lost 3 us over stages 1-3, the extra LDS
+//  round trip costing more than the partial loads at that occupancy.)
 // Branch-free on purpose: every load is issued unconditionally from a clamped (always valid) address and masked
 // afterwards.  hipcc's wait-count insertion falls back to s_waitcnt vmcnt(0) at control-flow joins, which would make
 // the wave wait for the look-ahead loads at the first conditional in the compute step; straight-line code gets exact
@@ -3336,9 +3339,10 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
              const double* __restrict__ Lf, const double* __restrict__ D, const int32_t* __restrict__ gperm,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, double* __restrict__ slotv,
-             double* __restrict__ cvec, Cols cs, const int32_t* __restrict__ pull2, int unit_tbeg) {
+             double* __restrict__ cvec, Cols cs, const int32_t* __restrict__ pull2, int unit_tbeg, int wimg_units) {
   constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
   __shared__ double accs[4][WSLOT * AS + 64];     // + a spare row (64 wide) for the masked lanes
+  extern __shared__ __attribute__((aligned(16))) double2_t wdyn[];    // wide launches: wimg_units 16-byte units per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GSLS_COLS;
   xp += col_ * cs.sx;
@@ -4005,6 +4009,8 @@ static hipError_t allow_big_lds() {
   // the wide backward launches of the wave tier stage one forward image per wave (up to 16 KB) beside their static LDS
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_bwd<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_bwd<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   return hipSuccess;
@@ -5175,8 +5181,9 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   auto wave_fwd = [&](int g0, int cnt, bool narrow, int unit = -1) {
     if (cnt <= 0) return;
 #define GSLS_WFWD(D_, N_, F_)                                                                                      \
-  hipLaunchKernelGGL((k_wsolve_fwd<D_, N_, F_>), dim3(((cnt + 3) / 4) * R), dim3(256), (N_) ? ws_pad : 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
-                     F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cs, F.wpull2, unit)
+  hipLaunchKernelGGL((k_wsolve_fwd<D_, N_, F_>), dim3(((cnt + 3) / 4) * R), dim3(256),                                        \
+                     (N_) ? ws_pad : 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
+                     F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cs, F.wpull2, unit, F.wimg_units)
     if (fuse_d) { if (narrow) { if (ws_flat) GSLS_WFWD(true, true, true); else GSLS_WFWD(true, true, false); } else GSLS_WFWD(true, false, false); }
     else { if (narrow) { if (ws_flat) GSLS_WFWD(false, true, true); else GSLS_WFWD(false, true, false); } else GSLS_WFWD(false, false, false); }
 #undef GSLS_WFWD

@@ -157,7 +157,7 @@ class SLS:
         # scaling, and wider supernodes than the CPU default of 32 (fewer, fatter fronts suit the GPU)
         control.ordering = -1
         control.scaling = 0
-        control.node_amalgamation = 64
+        control.node_amalgamation = 0       # the backend chooses from the tree it finds (gsls_analyse: 24 or 64)
 
     # -- SLS_coord_to_sorted_csr (sls.f90:8409-8578) -----------------------------------------------
     @staticmethod

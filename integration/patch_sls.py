@@ -20,7 +20,7 @@ ARMS = [
        CALL GSLS_initialize( data%gsls_keep, data%gsls_options )
        control%scaling = 0
        IF ( control%ordering == 0 ) control%ordering = - 1
-       control%node_amalgamation = 64
+       control%node_amalgamation = 0          ! the backend chooses from the tree it finds (24 or 64)
 
 """,
     # 1: SLS_initialize_solver (:1024)
