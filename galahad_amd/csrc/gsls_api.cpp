@@ -56,6 +56,8 @@ struct Handle {
   bool coo_uploaded = false;      // ... and its structure is on the device
   std::vector<int32_t> coo_row, coo_col, coo_map;
   int shard_repairs = 0;          // repair rounds of the sharded path (plan_repair's pass counter)
+  std::vector<int32_t> hint_pairs;   // 2x2 pivots of the last discovered sequence as VARIABLE pairs (v1, v2, v1, v2 ...):
+                                     // position hints are rebuilt from them after every re-analysis
   int learn_strikes = 0;          // factorizations in a row whose learned pivot sequence failed on the new values
   int tpp_useless = 0;            // flag-only repairs in a row after which every flagged column failed again
   bool eager_delay = false;       // ... twice: failing columns of one-block fronts go straight to the parent
@@ -728,6 +730,26 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     }
     return hipSuccess;
   };
+  // position hints from the variable pairs of the last discovery (the analysis postorders the tree and renumbers inside
+  // merged supernodes, so a pair is looked up where it sits NOW; one that is no longer adjacent loses its hint)
+  auto upload_pair_hints = [&]() -> hipError_t {
+    const int n = h->S.n;
+    if (h->hint_pairs.empty() || n == 0) return hipSuccess;
+    std::vector<uint8_t> hints(n, 0);
+    int lost = 0;
+    bool any2 = false;
+    for (size_t k = 0; k + 1 < h->hint_pairs.size(); k += 2) {
+      const int p1 = h->S.perm[h->hint_pairs[k]], p2 = h->S.perm[h->hint_pairs[k + 1]];
+      if (p2 == p1 + 1) { hints[p1] = 1; any2 = true; }
+      else if (p1 == p2 + 1) { hints[p2] = 1; any2 = true; }
+      else ++lost;
+    }
+    if (getenv("GSLS_DEBUG") && lost) fprintf(stderr, "[gsls] %d of %zu 2x2 pairs are not adjacent in the analysed order\n", lost, h->hint_pairs.size() / 2);
+    hipError_t e2 = hipMemcpy(F.hint, hints.data(), size_t(n), hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) return e2;
+    F.any_hint = any2;
+    return hipSuccess;
+  };
   {
     const bool fresh = !h->dev_ready;
     e = sync_device();
@@ -741,11 +763,30 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   int tiny_repeats = 0;
   const int max_pass = 60;    // a variable fails at most three times (plan_repair); cascades end long before this
   int pending_flags = 0;      // columns the last repair flagged for whole-front pivoting (without moving them)
+  bool discovered = false;    // the pivot-order discovery sweep has run in this call (dev_discover)
+  bool disc_ok = false;       // ... and its sequence was adopted
+  bool just_learned = false;  // the previous pass ended in a learning round
+  int learn_fail = 0;         // learning rounds of this call after which pivots failed
   for (int pass = 0;; ++pass) {
     // refactorizations of a learned order: tiny fronts whole, a wave each (k_front_tiny); if that kernel
     // meets a pivot it cannot take (stat[13]) the pass is repeated on the workgroup path
     bool any_tpp = false;
     for (const auto& c : F.tpp_cnt[0]) any_tpp |= (c > 0);
+    if (any_tpp && disc_ok && h->tiny_ready && !tiny_off && !posdef && !scale) {
+      // after a discovery the wave-per-front kernels stay in charge; the few fronts flagged for whole-front pivoting are
+      // taken out of their hands (blacklist: assembled in HBM, extend-add and contribution by the workgroup tasks,
+      // k_front_tpp for the factorization -- every workgroup kernel skips a flagged front)
+      std::vector<int32_t> bl(h->tiny_black);
+      for (int sn : tpp_nodes(h->S, h->tppvar)) bl.push_back(sn);
+      std::sort(bl.begin(), bl.end());
+      bl.erase(std::unique(bl.begin(), bl.end()), bl.end());
+      if (bl.size() != h->tiny_black.size()) {
+        h->tiny_black.swap(bl);
+        e = dev_set_tiny_blacklist(h->S, F, h->tiny_black, h->stream);
+        if (e != hipSuccess) return fail_hip(h, inform, e);
+      }
+      any_tpp = false;
+    }
     const bool use_tiny = !posdef && !scale && h->tiny_ready && !tiny_off && !any_tpp;
     e = dev_factor(h->S, F, posdef != 0, d_val, d_scale, options->small, options->u, h->stream, use_tiny);
     if (e != hipSuccess) return fail_hip(h, inform, e);
@@ -821,7 +862,14 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       else h->tpp_useless = 0;
       pending_flags = 0;
     }
-    if (!posdef && st[4] == 0 && h->learned < 3 && h->learn_strikes < 2 && (st[7] > 0 || st[14] > 0)) {
+    if (just_learned) {
+      // the learning round before this pass changed the order: if that broke pivots, this call stops learning and
+      // takes the first clean pass it gets (a valid factorization; learning only serves later refactorizations)
+      if (st[4] > 0) ++learn_fail;
+      just_learned = false;
+    }
+    if (!posdef && st[4] == 0 && h->learned < 3 && h->learn_strikes < 2 && learn_fail == 0 && (st[7] > 0 || st[14] > 0)) {
+      just_learned = true;
       // ---- learn: fold the pivot sequence the pivoting kernels chose inside their blocks / fronts into the
       // elimination order, and remember where they took 2x2 pivots, so that later factorizations of
       // this pattern (the next interior-point iterations) go through the optimistic kernel
@@ -859,6 +907,9 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
           moved = true;
         }
       for (int i = 0; i < n; ++i) order[seq[i]] = i + 1;
+      h->hint_pairs.clear();                 // (the learned pairs replace those of an earlier discovery)
+      for (int i = 0; i + 1 < n; ++i)
+        if (hints[i]) { h->hint_pairs.push_back(seq[i]); h->hint_pairs.push_back(seq[i + 1]); }
       // the learned sequence is tried on the blocked kernels again: whole-front pivoting only where it is
       // needed once more
       const bool had_flags = !h->tpp_unflagged && !h->tppvar.empty() &&
@@ -885,7 +936,72 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       if (moved) continue;     // factorize once more in the learned order
     }
     if (posdef || st[4] == 0) break;
-    // ---- some pivots failed: flag their fronts for whole-front pivoting, or (second failure) move them up ----
+    // ---- some pivots failed.  First choice (once per factorization, trees of wavefront-sized fronts): let the device
+    // find the elimination sequence threshold partial pivoting WITH run-time delays gives for these values
+    // (k_front_discover: one bottom-up sweep, failed columns travel to the parent inside it, as in the reference),
+    // adopt it as the order + 2x2 hints, re-analyse once and factorize again on the static kernels ---------------------
+    if (!discovered && !scale && !getenv("GSLS_NO_DISCOVER")) {
+      discovered = true;
+      std::vector<int32_t> seq;
+      std::vector<uint8_t> two;
+      int dstat = 1, ndel = 0;
+      const double td = now();
+      e = dev_discover(h->S, F, d_val, options->small, options->u, h->stream, seq, two, dstat, ndel);
+      if (e != hipSuccess) return fail_hip(h, inform, e);
+      if (dstat == 0) {
+        const int n = h->S.n;
+        std::vector<int32_t> order(n);
+        for (int i = 0; i < n; ++i) order[seq[i]] = i + 1;
+        // a variable that was eliminated in another front than the one the analysis gave it must share a supernode
+        // with the columns it now sits between (relaxed_supernodes: force)
+        if (int(h->force.size()) != n) h->force.assign(n, 0);
+        {
+          const Symbolic& S0 = h->S;
+          // (the new supernode ranges are not known yet: compare every variable's OLD supernode with its neighbour's)
+          std::vector<int32_t> oldsn(n);
+          for (int sn = 0; sn < S0.nnodes; ++sn)
+            for (int pcol = S0.sptr[sn]; pcol < S0.sptr[sn + 1]; ++pcol) oldsn[S0.invp[pcol]] = sn;
+          for (int i = 0; i + 1 < n; ++i)
+            if (oldsn[seq[i]] < oldsn[seq[i + 1]] && S0.perm[seq[i]] + 1 != S0.perm[seq[i + 1]]) {
+              // seq[i] comes from a descendant front and now precedes a column of an ancestor: a delayed pivot
+              int a = oldsn[seq[i]];
+              bool anc = false;
+              while (a < S0.nnodes && !anc) { a = S0.sparent[a]; anc = (a == oldsn[seq[i + 1]]); }
+              if (anc) h->force[seq[i]] = 1;
+            }
+        }
+        std::fill(h->tppvar.begin(), h->tppvar.end(), uint8_t(0));
+        std::fill(h->tppfail.begin(), h->tppfail.end(), uint8_t(0));
+        h->tpp_dirty = true;
+        // the next pass takes the wave-per-front kernels: k_front_blk eliminates hinted 2x2 pivots wherever they sit
+        // (its panels are cut around them), where the 16-column stages of the workgroup kernel cannot take a pair
+        // that straddles two stages -- and a sequence found by threshold pivoting has pairs everywhere
+        h->tiny_ready = !getenv("GSLS_DISCOVER_WG");
+        tiny_off = false;
+        tiny_repeats = 0;
+        h->tiny_black.clear();
+        h->learned = 0;
+        int rf = reanalyse(h, order, inform);
+        if (rf < 0) return inform->flag = rf;
+        // The analysis postorders the elimination tree, so columns that do not depend on each other may have changed
+        // places: the 2x2 hints go by VARIABLE pair to wherever the pair sits now (a pair that is no longer adjacent
+        // loses its hint and is left to the repair loop; the wave-per-front kernels that run next take a pair anywhere
+        // in a front, so no adjustment to the 16-column stages of the workgroup kernel is made here)
+        h->hint_pairs.clear();
+        for (int i = 0; i + 1 < n; ++i)
+          if (two[i]) { h->hint_pairs.push_back(seq[i]); h->hint_pairs.push_back(seq[i + 1]); }
+        disc_ok = true;
+        e = sync_device();
+        if (e == hipSuccess) e = upload_pair_hints();
+        if (e != hipSuccess) { h->dev_ready = false; return fail_hip(h, inform, e); }
+        total_moved += ndel;
+        if (getenv("GSLS_DEBUG"))
+          fprintf(stderr, "[gsls] discovery: %d delayed columns, order + hints adopted in %.3f s\n", ndel, now() - td);
+        continue;
+      }
+      if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] discovery: not applicable to this tree / these values\n");
+    }
+    // ---- otherwise: flag their fronts for whole-front pivoting, or (second failure) move them up ----
     const int nf = std::min<int>(st[5], FAILCAP);
     std::vector<int32_t> failed(nf);
     if (nf > 0) {
@@ -909,8 +1025,8 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     }
     if (rp.flagged && !rp.reorder) pending_flags = int(failed.size());
     total_moved += int(failed.size());
-    h->tiny_ready = false;
-    h->tiny_black.clear();
+    if (!disc_ok) h->tiny_ready = false;      // (after a discovery the wave-per-front kernels keep the rest of the tree)
+    if (!disc_ok || rp.reorder) h->tiny_black.clear();
     h->tpp_dirty = true;
     const double ta = now();
     if (rp.reorder) {
@@ -920,6 +1036,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     }
     const double tb = now();
     e = sync_device();
+    if (e == hipSuccess && disc_ok && rp.reorder) e = upload_pair_hints();
     if (e != hipSuccess) { h->dev_ready = false; return fail_hip(h, inform, e); }
     if (getenv("GSLS_DEBUG"))
       fprintf(stderr, "[gsls] repair (%s): re-analysis %.3f s, plan + upload %.3f s\n", rp.reorder ? "order" : "flags", tb - ta, now() - tb);

@@ -3602,6 +3602,431 @@ k_wsolve_tail(WTail tl, const WGroup* __restrict__ groups, const WTask* __restri
   }
 }
 
+// =================================================================================================
+// PIVOT-ORDER DISCOVERY (round 3): run-time delayed pivots, confined to one kernel.
+// The reference carries a column that fails the threshold test into the parent front during the pass
+// (assemble.hxx:244-264, factor.hxx:57-106, ldlt_tpp.cxx:140-240).  The product kernels here are statically scheduled
+// and sized, so until now a failure cost a host round trip per LEVEL of the delay cascade (flag, move to the parent,
+// re-analyse, another pass: 10-20 passes for an interior-point KKT system late in the run).  This kernel does what the
+// reference does -- threshold partial pivoting over ALL fully-summed columns of a front, 1x1 and 2x2 pivots, what cannot
+// be eliminated handed to the parent together with its rows of the Schur complement -- in ONE bottom-up sweep, for trees
+// whose fronts (delays included) fit a wavefront: a wave per front, the front as a full symmetric matrix in LDS, lane =
+// row.  It does not produce factors: its output is the ELIMINATION SEQUENCE it found (per front: the variables in pivot
+// order, 2x2 pairs marked).  The host turns that into an order + hints, re-analyses ONCE, and the static kernels factorize
+// in that order (gsls_api.cpp, pass loop).  A front that would exceed 64 rows, or pass up more than DISC_DCAP columns,
+// raises the overflow flag and the old repair loop takes over.
+//   work matrix indices: [0, din) columns delayed by the children (child order), [din, din + n) own pivots,
+//   [din + n, din + m) contribution rows; candidates = [0, din + n).
+// =================================================================================================
+constexpr int DISC_LD = 65, DISC_DCAP = 12;      // wave fronts: at most 64 rows with their incoming delays, 12 delays out
+constexpr int DISC_WIDE_M = 48;                  // fronts with more rows than this take the workgroup form:
+constexpr int DISC_WIDE_IN = 64, DISC_WIDE_OUT = 64, DISC_WIDE_MAX = 512;   // up to 64 delays in / out, 512 rows in all
+struct DiscTask {                   // per front, indexed by node
+  int32_t m, n, sptr, parent;
+  int32_t cbeg, ccnt, moff, qcap;   // children in clist; its child->parent map; row stride of its block in the arena
+  int64_t a0, coff;                 // its entries of A (asrc / arc); its block in the discovery arena
+  int32_t acnt, dcap;               // ... ; delays it may pass up
+  int64_t woff;                     // workgroup form: its work matrix in the scratch (mcap x mcap, column-major)
+  int32_t mcap, wide;
+  int64_t voff, poff;               // its delayed variables in dvar, its elimination sequence in pseq / ptwo
+};
+__device__ __forceinline__ double disc_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__global__ void __launch_bounds__(256)
+k_front_discover(const DiscTask* __restrict__ tasks, const int32_t* __restrict__ list, int cnt,
+                 const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap, const int32_t* __restrict__ invp,
+                 const int64_t* __restrict__ asrc, const uint32_t* __restrict__ arc, const double* __restrict__ val,
+                 double* __restrict__ arena, int32_t* __restrict__ ddelay, int32_t* __restrict__ dvar,
+                 int32_t* __restrict__ pseq, uint8_t* __restrict__ ptwo, int32_t* __restrict__ pcnt,
+                 int32_t* __restrict__ flags, double small, double u, int nn) {
+  extern __shared__ __attribute__((aligned(16))) double dsh[];
+  __shared__ int idsh[4][64];
+  __shared__ int twosh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (ti >= cnt) return;
+  const int s = list[ti];
+  const DiscTask t = tasks[s];
+  double* W = dsh + wave * (64 * DISC_LD);
+  int* ids = idsh[wave];
+  int* two = twosh[wave];
+#define DSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+  int din = 0;
+  for (int ci = 0; ci < t.ccnt; ++ci) din += ddelay[clist[t.cbeg + ci]];
+  din = __builtin_amdgcn_readfirstlane(din);
+  const int M = din + t.m, nc = din + t.n;
+  if (M > 64) {                                     // does not fit a wavefront: the whole discovery is void
+    if (lane == 0) { atomicOr(&flags[0], 1); ddelay[s] = 0; pcnt[s] = 0; }
+    return;
+  }
+  for (int c = 0; c < M; ++c) W[lane * DISC_LD + c] = 0.0;
+  ids[lane] = (lane >= din && lane < nc) ? invp[t.sptr + lane - din] : -1;
+  two[lane] = 0;
+  DSYNC();
+  // own entries of A (lower triangle of the front, both halves of the symmetric work matrix)
+  for (int e = lane; e < t.acnt; e += 64) {
+    const uint32_t rc = arc[t.a0 + e];
+    const int r = din + int(rc & 0xffffu), c = din + int(rc >> 16);
+    const double v = val[asrc[t.a0 + e]];
+    W[r * DISC_LD + c] = v;
+    W[c * DISC_LD + r] = v;
+  }
+  DSYNC();
+  // the children's Schur complements: delayed columns first, then their contribution rows
+  {
+    int base = 0;
+    for (int ci = 0; ci < t.ccnt; ++ci) {
+      const int c = clist[t.cbeg + ci];
+      const DiscTask tc = tasks[c];
+      const int dc = __builtin_amdgcn_readfirstlane(ddelay[c]);
+      const int q = dc + tc.m - tc.n;
+      if (lane < dc) ids[base + lane] = dvar[tc.voff + lane];
+      const int mi = (lane < dc) ? base + lane : ((lane < q) ? din + cmap[tc.moff + lane - dc] : 0);
+      const double* Cb = arena + tc.coff;
+      for (int j = 0; j < q; ++j) {
+        const int mj = __shfl(mi, j);
+        if (lane < q) W[mi * DISC_LD + mj] += Cb[int64_t(lane) * tc.qcap + j];
+      }
+      base += dc;
+      DSYNC();
+    }
+  }
+  // ---- threshold partial pivoting over the candidates [0, nc), rows [0, M): the rules of ldlt_tpp.cxx:140-240 ------
+  auto colmax = [&](int col, int from, int x1, int x2) -> double {
+    const double v = (lane >= from && lane < M && lane != x1 && lane != x2) ? fabs(W[lane * DISC_LD + col]) : 0.0;
+    return disc_wave_max(v);
+  };
+  auto swap_sym = [&](int x, int y) {
+    if (x == y) return;
+    {
+      const double a = W[lane * DISC_LD + x], b = W[lane * DISC_LD + y];
+      W[lane * DISC_LD + x] = b;
+      W[lane * DISC_LD + y] = a;
+    }
+    DSYNC();
+    {
+      const double a = W[x * DISC_LD + lane], b = W[y * DISC_LD + lane];
+      W[x * DISC_LD + lane] = b;
+      W[y * DISC_LD + lane] = a;
+    }
+    if (lane == 0) { const int v = ids[x]; ids[x] = ids[y]; ids[y] = v; }
+    DSYNC();
+  };
+  auto pivot_1x1 = [&](int p) {
+    const double d = 1.0 / W[p * DISC_LD + p];
+    const double lrp = W[lane * DISC_LD + p];
+    if (lane > p && lane < M)
+      for (int c = p + 1; c < M; ++c) W[lane * DISC_LD + c] -= (lrp * W[c * DISC_LD + p]) * d;
+    DSYNC();
+  };
+  auto pivot_2x2 = [&](int p, double d11, double d21, double d22) {
+    const double a1r = W[lane * DISC_LD + p], a2r = W[lane * DISC_LD + p + 1];
+    if (lane > p + 1 && lane < M)
+      for (int c = p + 2; c < M; ++c) {
+        const double a1c = W[c * DISC_LD + p], a2c = W[c * DISC_LD + p + 1];
+        W[lane * DISC_LD + c] -= d11 * (a1r * a1c) + d21 * (a2r * a1c + a1r * a2c) + d22 * (a2r * a2c);
+      }
+    DSYNC();
+  };
+  int p = 0;
+  while (p < nc) {
+    if (colmax(p, p, -1, -1) < small) { ++p; continue; }            // a zero pivot (ldlt_tpp.cxx:150-160)
+    bool found = false;
+    for (int q = p + 1; q < nc && !found; ++q) {
+      const double aq = (lane >= p && lane < M) ? fabs(W[lane * DISC_LD + q]) : 0.0;
+      const double mall = disc_wave_max(aq);
+      if (mall < small) {
+        swap_sym(p, q);
+        ++p;
+        found = true;
+        break;
+      }
+      // largest entry of column q among the rows [p, q): smallest index on ties
+      const double mv = disc_wave_max((lane >= p && lane < q) ? aq : -1.0);
+      const unsigned long long hit = __ballot((lane >= p && lane < q) && aq == mv);
+      const int tt = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)hit)) - 1);
+      const double maxt = colmax(tt, p, tt, q);
+      double maxq = colmax(q, p, q, tt);
+      const double a11 = W[tt * DISC_LD + tt], a21 = W[q * DISC_LD + tt], a22 = W[q * DISC_LD + q];
+      bool ok2 = false;
+      double d11 = 0.0, d21 = 0.0, d22 = 0.0;
+      const double maxpiv = fmax(fabs(a11), fmax(fabs(a21), fabs(a22)));
+      if (maxpiv >= small) {                       // test_2x2 (ldlt_tpp.cxx:99-130)
+        const double detscale = 1.0 / maxpiv;
+        const double detpiv0 = (a11 * detscale) * a22, detpiv1 = (a21 * detscale) * a21;
+        const double detpiv = detpiv0 - detpiv1;
+        if (!(fabs(detpiv) < fmax(small, fmax(fabs(detpiv0 / 2), fabs(detpiv1 / 2))))) {
+          d11 = (a22 * detscale) / detpiv;
+          d21 = (-a21 * detscale) / detpiv;
+          d22 = (a11 * detscale) / detpiv;
+          if (fmax(maxq, maxt) < small) ok2 = true;
+          else {
+            const double x1 = fabs(d11) * maxt + fabs(d21) * maxq;
+            const double x2 = fabs(d21) * maxt + fabs(d22) * maxq;
+            ok2 = (u * fmax(x1, x2) < 1.0);
+          }
+        }
+      }
+      if (ok2) {
+        swap_sym(tt, p);
+        swap_sym(q, p + 1);
+        pivot_2x2(p, d11, d21, d22);
+        if (lane == 0) two[p] = 1;
+        p += 2;
+        found = true;
+        break;
+      }
+      maxq = fmax(maxq, fabs(a21));
+      if (fabs(a22) >= u * maxq && fabs(a22) >= small) {
+        swap_sym(q, p);
+        pivot_1x1(p);
+        p += 1;
+        found = true;
+        break;
+      }
+    }
+    if (found) continue;
+    const double maxp = colmax(p, p, p, -1);
+    const double app = W[p * DISC_LD + p];
+    if (fabs(app) >= u * maxp && fabs(app) >= small) {
+      pivot_1x1(p);
+      ++p;
+    } else {
+      break;                                       // no more pivots in this front: the rest is delayed
+    }
+  }
+  DSYNC();
+  const bool root = t.parent >= nn;
+  const int nelim = p;
+  const int count = root ? nc : nelim;             // (a root keeps what is left: zero pivots)
+  const int dout = root ? 0 : nc - nelim;
+  if (dout > t.dcap) {
+    if (lane == 0) { atomicOr(&flags[0], 2); ddelay[s] = 0; pcnt[s] = 0; }
+    return;
+  }
+  if (lane < count) {
+    pseq[t.poff + lane] = ids[lane];
+    ptwo[t.poff + lane] = uint8_t(two[lane]);
+  }
+  if (lane < dout) dvar[t.voff + lane] = ids[nelim + lane];
+  if (lane == 0) {
+    pcnt[s] = count;
+    ddelay[s] = dout;
+    if (dout > 0) atomicAdd(&flags[1], dout);
+  }
+  if (!root) {
+    const int q = dout + t.m - t.n;                // what goes to the parent: leftover candidates, then the contribution rows
+    double* Cb = arena + t.coff;
+    if (lane < q)
+      for (int j = 0; j < q; ++j) Cb[int64_t(lane) * t.qcap + j] = W[(nelim + lane) * DISC_LD + nelim + j];
+  }
+#undef DSYNC
+}
+
+// The same for a front beyond a wavefront (up to DISC_WIDE_MAX rows with its incoming delays): one workgroup, the work
+// matrix full symmetric and column-major in a global scratch area (few such fronts: the top of a saddle-point tree, or
+// what earlier order repairs have gathered at a root), thread = row.  Same rules, same outputs.
+__global__ void __launch_bounds__(256)
+k_front_discover_wg(const DiscTask* __restrict__ tasks, const int32_t* __restrict__ list, int cnt,
+                    const int32_t* __restrict__ clist, const int32_t* __restrict__ cmap, const int32_t* __restrict__ invp,
+                    const int64_t* __restrict__ asrc, const uint32_t* __restrict__ arc, const double* __restrict__ val,
+                    double* __restrict__ arena, double* __restrict__ scratch, int32_t* __restrict__ ddelay,
+                    int32_t* __restrict__ dvar, int32_t* __restrict__ pseq, uint8_t* __restrict__ ptwo,
+                    int32_t* __restrict__ pcnt, int32_t* __restrict__ flags, double small, double u, int nn) {
+  __shared__ double redv[8];
+  __shared__ int redi[4];
+  __shared__ int ids[DISC_WIDE_MAX], two[DISC_WIDE_MAX], mapi[DISC_WIDE_MAX];
+  const int tid = threadIdx.x;
+  const int s = list[blockIdx.x];
+  const DiscTask t = tasks[s];
+  int din = 0;
+  for (int ci = 0; ci < t.ccnt; ++ci) din += ddelay[clist[t.cbeg + ci]];
+  const int M = din + t.m, nc = din + t.n;
+  if (M > t.mcap) {
+    if (tid == 0) { atomicOr(&flags[0], 1); ddelay[s] = 0; pcnt[s] = 0; }
+    return;
+  }
+  const int64_t ld = t.mcap;
+  double* W = scratch + t.woff;                     // W(r, c) = W[c * ld + r]
+  for (int c = 0; c < M; ++c)
+    for (int r = tid; r < M; r += 256) W[c * ld + r] = 0.0;
+  for (int i = tid; i < M; i += 256) {
+    ids[i] = (i >= din && i < nc) ? invp[t.sptr + i - din] : -1;
+    two[i] = 0;
+  }
+  tpp_sync();
+  for (int e = tid; e < t.acnt; e += 256) {
+    const uint32_t rc = arc[t.a0 + e];
+    const int r = din + int(rc & 0xffffu), c = din + int(rc >> 16);
+    const double v = val[asrc[t.a0 + e]];
+    W[c * ld + r] = v;
+    W[r * ld + c] = v;
+  }
+  tpp_sync();
+  {
+    int base = 0;
+    for (int ci = 0; ci < t.ccnt; ++ci) {
+      const int c = clist[t.cbeg + ci];
+      const DiscTask tc = tasks[c];
+      const int dc = ddelay[c];
+      const int q = dc + tc.m - tc.n;
+      for (int i = tid; i < q; i += 256) {
+        if (i < dc) ids[base + i] = dvar[tc.voff + i];
+        mapi[i] = (i < dc) ? base + i : din + cmap[tc.moff + i - dc];
+      }
+      tpp_sync();
+      const double* Cb = arena + tc.coff;
+      for (int64_t e = tid; e < int64_t(q) * q; e += 256) {
+        const int i = int(e / q), j = int(e % q);
+        W[int64_t(mapi[j]) * ld + mapi[i]] += Cb[int64_t(i) * tc.qcap + j];   // (one thread per target: the map is injective)
+      }
+      base += dc;
+      tpp_sync();
+    }
+  }
+  auto colmax = [&](int col, int from, int x1, int x2) -> double {
+    double v = 0.0;
+    for (int i = from + tid; i < M; i += 256)
+      if (i != x1 && i != x2) v = fmax(v, fabs(W[col * ld + i]));
+    return tpp_max(v, redv);
+  };
+  auto swap_sym = [&](int x, int y) {
+    if (x == y) return;
+    for (int r = tid; r < M; r += 256) {
+      const double a = W[x * ld + r], b = W[y * ld + r];
+      W[x * ld + r] = b;
+      W[y * ld + r] = a;
+    }
+    tpp_sync();
+    for (int c = tid; c < M; c += 256) {
+      const double a = W[c * ld + x], b = W[c * ld + y];
+      W[c * ld + x] = b;
+      W[c * ld + y] = a;
+    }
+    if (tid == 0) { const int v = ids[x]; ids[x] = ids[y]; ids[y] = v; }
+    tpp_sync();
+  };
+  auto pivot_1x1 = [&](int p) {
+    const double d = 1.0 / W[p * ld + p];
+    for (int c = p + 1; c < M; ++c) {
+      const double acp = W[p * ld + c];
+      for (int r = p + 1 + tid; r < M; r += 256) W[c * ld + r] -= (W[p * ld + r] * acp) * d;
+    }
+    tpp_sync();
+  };
+  auto pivot_2x2 = [&](int p, double d11, double d21, double d22) {
+    for (int c = p + 2; c < M; ++c) {
+      const double a1c = W[p * ld + c], a2c = W[(p + 1) * ld + c];
+      for (int r = p + 2 + tid; r < M; r += 256) {
+        const double a1r = W[p * ld + r], a2r = W[(p + 1) * ld + r];
+        W[c * ld + r] -= d11 * (a1r * a1c) + d21 * (a2r * a1c + a1r * a2c) + d22 * (a2r * a2c);
+      }
+    }
+    tpp_sync();
+  };
+  int p = 0;
+  while (p < nc) {
+    if (colmax(p, p, -1, -1) < small) { ++p; continue; }
+    bool found = false;
+    for (int q = p + 1; q < nc && !found; ++q) {
+      double mall = 0.0, mv = -1.0;
+      int mi = INT_MAX;
+      for (int i = p + tid; i < M; i += 256) {
+        const double a = fabs(W[q * ld + i]);
+        mall = fmax(mall, a);
+        if (i < q && (a > mv || (a == mv && i < mi))) { mv = a; mi = i; }
+      }
+      mall = tpp_max(mall, redv);
+      if (mall < small) {
+        swap_sym(p, q);
+        ++p;
+        found = true;
+        break;
+      }
+      tpp_argmax(mv, mi, redv + 4, redi);
+      const int tt = mi;
+      const double maxt = colmax(tt, p, tt, q);
+      double maxq = colmax(q, p, q, tt);
+      const double a11 = W[tt * ld + tt], a21 = W[tt * ld + q], a22 = W[q * ld + q];
+      bool ok2 = false;
+      double d11 = 0.0, d21 = 0.0, d22 = 0.0;
+      const double maxpiv = fmax(fabs(a11), fmax(fabs(a21), fabs(a22)));
+      if (maxpiv >= small) {
+        const double detscale = 1.0 / maxpiv;
+        const double detpiv0 = (a11 * detscale) * a22, detpiv1 = (a21 * detscale) * a21;
+        const double detpiv = detpiv0 - detpiv1;
+        if (!(fabs(detpiv) < fmax(small, fmax(fabs(detpiv0 / 2), fabs(detpiv1 / 2))))) {
+          d11 = (a22 * detscale) / detpiv;
+          d21 = (-a21 * detscale) / detpiv;
+          d22 = (a11 * detscale) / detpiv;
+          if (fmax(maxq, maxt) < small) ok2 = true;
+          else {
+            const double x1 = fabs(d11) * maxt + fabs(d21) * maxq;
+            const double x2 = fabs(d21) * maxt + fabs(d22) * maxq;
+            ok2 = (u * fmax(x1, x2) < 1.0);
+          }
+        }
+      }
+      if (ok2) {
+        swap_sym(tt, p);
+        swap_sym(q, p + 1);
+        pivot_2x2(p, d11, d21, d22);
+        if (tid == 0) two[p] = 1;
+        p += 2;
+        found = true;
+        break;
+      }
+      maxq = fmax(maxq, fabs(a21));
+      if (fabs(a22) >= u * maxq && fabs(a22) >= small) {
+        swap_sym(q, p);
+        pivot_1x1(p);
+        p += 1;
+        found = true;
+        break;
+      }
+    }
+    if (found) continue;
+    const double maxp = colmax(p, p, p, -1);
+    const double app = W[p * ld + p];
+    if (fabs(app) >= u * maxp && fabs(app) >= small) {
+      pivot_1x1(p);
+      ++p;
+    } else {
+      break;
+    }
+  }
+  tpp_sync();
+  const bool root = t.parent >= nn;
+  const int nelim = p;
+  const int count = root ? nc : nelim;
+  const int dout = root ? 0 : nc - nelim;
+  if (dout > t.dcap) {
+    if (tid == 0) { atomicOr(&flags[0], 2); ddelay[s] = 0; pcnt[s] = 0; }
+    return;
+  }
+  for (int i = tid; i < count; i += 256) {
+    pseq[t.poff + i] = ids[i];
+    ptwo[t.poff + i] = uint8_t(two[i]);
+  }
+  for (int i = tid; i < dout; i += 256) dvar[t.voff + i] = ids[nelim + i];
+  if (tid == 0) {
+    pcnt[s] = count;
+    ddelay[s] = dout;
+    if (dout > 0) atomicAdd(&flags[1], dout);
+  }
+  if (!root) {
+    const int q = dout + t.m - t.n;
+    double* Cb = arena + t.coff;
+    for (int64_t e = tid; e < int64_t(q) * q; e += 256) {
+      const int i = int(e / q), j = int(e % q);
+      Cb[int64_t(i) * t.qcap + j] = W[int64_t(nelim + j) * ld + nelim + i];
+    }
+  }
+}
+
 // gvar[slot] = variable eliminated at pivot slot `slot` (after the numerical pivoting of this factorization)
 __global__ void k_gvar(int n, const int32_t* __restrict__ gperm, const int32_t* __restrict__ invp,
                        int32_t* __restrict__ gvar) {
@@ -3966,7 +4391,9 @@ void dev_free(DeviceFactor& F) {
                   F.acol, F.ptasks, F.ttasks, F.invp, F.L, F.C, F.D, F.val, F.scale, F.xp, F.cvec, F.xp_mr, F.cvec_mr,
                   F.xhost, F.stat, F.gperm, F.pulltasks, F.faillist, F.smallnodes, F.bignodes, F.bigtrsv,
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
-                  F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wpull2, F.wnont, F.Lf, F.Lb, F.xs, F.gvar};
+                  F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wpull2, F.wnont, F.Lf, F.Lb, F.xs, F.gvar,
+                  F.disc_tasks, F.disc_arc, F.disc_ddelay, F.disc_dvar, F.disc_pseq, F.disc_pcnt, F.disc_flags, F.disc_ptwo, F.disc_arena,
+                  F.disc_scratch, F.disc_list};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : {static_cast<void*>(F.mc_xp), static_cast<void*>(F.mc_xs), static_cast<void*>(F.mc_cvec),
@@ -4011,6 +4438,7 @@ static hipError_t allow_big_lds() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_bwd<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_discover), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * DISC_LD * 8));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   return hipSuccess;
@@ -4750,6 +5178,11 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
       hipLaunchKernelGGL(k_assemble_pull, dim3(lp.pull_cnt), dim3(256), 0, st,
                          static_cast<const PullTask*>(F.pulltasks) + lp.pull_begin,
                          static_cast<const PullSeg*>(F.pullsegs), F.cmap, F.L, F.C);
+    const bool bl_here = !POSDEF && &plan == &F.planT && l < int(F.bl_level.size()) && F.bl_level[l].np > 0;
+    if (bl_here && F.bl_level[l].npull > 0)    // before k_front_tpp: a blacklisted front may be flagged as well
+      hipLaunchKernelGGL(k_assemble_pull, dim3(F.bl_level[l].npull), dim3(256), 0, st,
+                         static_cast<const PullTask*>(F.bl_pulltasks) + F.bl_level[l].pullbeg,
+                         static_cast<const PullSeg*>(F.bl_pullsegs), F.cmap, F.L, F.C);
     if (!POSDEF && !F.tpp_cnt[which].empty() && F.tpp_cnt[which][l] > 0)   // fronts flagged for whole-front pivoting
       hipLaunchKernelGGL(k_front_tpp, dim3(F.tpp_cnt[which][l]), dim3(256), 0, st, F.nodes,
                          F.tpplist + F.tpp_begin[which][l], F.L, F.D, F.gperm, F.stat, F.faillist, small, u, S.nnodes);
@@ -4845,13 +5278,9 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
                              F.ptasks + lp.panel_begin[2 * s + 1], F.L, F.D, F.gperm, F.stat, F.faillist, u, F.tppflag, small);
       }
     }
-    if (!POSDEF && &plan == &F.planT && l < int(F.bl_level.size()) && F.bl_level[l].np > 0) {
+    if (bl_here) {
       // tiny fronts that k_front_tiny could not take (blacklisted by the host): the workgroup kernels
       const BlLevel& b = F.bl_level[l];
-      if (b.npull > 0)
-        hipLaunchKernelGGL(k_assemble_pull, dim3(b.npull), dim3(256), 0, st,
-                           static_cast<const PullTask*>(F.bl_pulltasks) + b.pullbeg,
-                           static_cast<const PullSeg*>(F.bl_pullsegs), F.cmap, F.L, F.C);
       const int nrt = std::max(NB / 16, (b.rows + 15) / 16);
       const int ldq = (16 * nrt) % 32 == 16 ? 16 * nrt : 16 * nrt + 16;
       const size_t lds_fldl = sizeof(double) * ldq * (NB + 16);
@@ -4885,6 +5314,9 @@ hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std:
   std::vector<uint8_t> skip(std::max(nn, 1), 0);
   std::vector<std::vector<int>> per(S.nlevels);
   for (int s : nodes) {
+    // (a front the tiny plan gives to the workgroup kernels anyway has its tasks in the plan: listing it here as well
+    // would assemble it twice)
+    if (!(S.ncol(s) <= TINY_N && S.nrow(s) <= 64)) continue;
     skip[s] = 1;
     per[S.level[s]].push_back(s);
   }
@@ -5115,6 +5547,139 @@ hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int
 static hipError_t ensure_linv(DeviceFactor& F) {
   if (F.Linv) return hipSuccess;
   return hipMalloc(reinterpret_cast<void**>(&F.Linv), std::max<int64_t>(F.nblk64, 1) * NB * NB * sizeof(double));
+}
+
+hipError_t dev_discover(const Symbolic& S, DeviceFactor& F, const double* d_val, double small, double u, hipStream_t st,
+                        std::vector<int32_t>& seq, std::vector<uint8_t>& two, int& status, int& ndelayed) {
+  const int nn = S.nnodes, n = S.n;
+  status = 1;
+  ndelayed = 0;
+  const int biggest = std::max(S.maxrow, S.maxfront);
+  if (nn == 0 || F.sharded || biggest + DISC_WIDE_IN > DISC_WIDE_MAX || !F.asrc) {
+    if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] discovery: tree not eligible (largest front %d rows)\n", biggest);
+    return hipSuccess;
+  }
+  if (!F.disc_tasks) {
+    std::vector<DiscTask> dt(nn);
+    int64_t off = 0, woff = 0, voff = 0, poff = 0;
+    for (int s = 0; s < nn; ++s) {
+      DiscTask& t = dt[s];
+      t.m = S.nrow(s);
+      t.n = S.ncol(s);
+      t.sptr = S.sptr[s];
+      t.parent = S.sparent[s];
+      t.cbeg = S.cptr[s];
+      t.ccnt = S.cptr[s + 1] - S.cptr[s];
+      t.moff = S.cmapptr[s];
+      t.wide = t.m > DISC_WIDE_M ? 1 : 0;
+      t.dcap = t.wide ? DISC_WIDE_OUT : DISC_DCAP;
+      t.mcap = t.wide ? t.m + DISC_WIDE_IN : 64;
+      t.qcap = (t.m - t.n) + t.dcap;
+      t.a0 = S.nptr[s];
+      t.acnt = int32_t(S.nptr[s + 1] - S.nptr[s]);
+      t.coff = off;
+      off += int64_t(t.qcap) * t.qcap;
+      t.woff = woff;
+      if (t.wide) woff += int64_t(t.mcap) * t.mcap;
+      t.voff = voff;
+      voff += t.dcap;
+      t.poff = poff;
+      poff += t.mcap;
+    }
+    F.disc_pcap = poff;
+    if ((woff + off) * 8 > (int64_t(16) << 30)) {       // (trees of many mid-sized fronts: not what this sweep is for)
+      if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] discovery: tree not eligible (%.1f GB of work matrices)\n", (woff + off) * 8e-9);
+      return hipSuccess;
+    }
+    std::vector<uint32_t> arc(std::max<int64_t>(S.nptr[nn], 1));
+    for (int s = 0; s < nn; ++s) {
+      const int64_t m = S.nrow(s);
+      for (int64_t k = S.nptr[s]; k < S.nptr[s + 1]; ++k) {
+        const int64_t dst = S.nlist[2 * k + 1];
+        arc[k] = uint32_t(dst % m) | (uint32_t(dst / m) << 16);
+      }
+    }
+    // per level: the wave fronts first, then the workgroup fronts
+    std::vector<int32_t> dl(S.lvlnodes.size());
+    F.disc_lvl_wide.assign(S.nlevels, 0);
+    for (int l = 0; l < S.nlevels; ++l) {
+      int a = S.lvlptr[l], b = S.lvlptr[l + 1];
+      int k = a;
+      for (int i = a; i < b; ++i)
+        if (!dt[S.lvlnodes[i]].wide) dl[k++] = S.lvlnodes[i];
+      F.disc_lvl_wide[l] = b - k;
+      for (int i = a; i < b; ++i)
+        if (dt[S.lvlnodes[i]].wide) dl[k++] = S.lvlnodes[i];
+    }
+    DiscTask* d = nullptr;
+    HIPCHK(upload(d, dt, st));
+    F.disc_tasks = d;
+    HIPCHK(upload(F.disc_arc, arc, st));
+    HIPCHK(upload(F.disc_list, dl, st));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_ddelay), size_t(nn) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_dvar), size_t(std::max<int64_t>(voff, 1)) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_pseq), size_t(std::max<int64_t>(poff, 1)) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_ptwo), size_t(std::max<int64_t>(poff, 1))));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_pcnt), size_t(nn) * sizeof(int32_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_flags), 4 * sizeof(int32_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_arena), size_t(std::max<int64_t>(off, 1)) * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_scratch), size_t(std::max<int64_t>(woff, 1)) * sizeof(double)));
+    F.disc_host.assign(dt.size() * 2, 0);        // (poff, mcap) per front for the read-back
+    for (int s = 0; s < nn; ++s) { F.disc_host[2 * s] = dt[s].poff; F.disc_host[2 * s + 1] = dt[s].mcap; }
+  }
+  HIPCHK(hipMemsetAsync(F.disc_ddelay, 0, size_t(nn) * sizeof(int32_t), st));
+  HIPCHK(hipMemsetAsync(F.disc_pcnt, 0, size_t(nn) * sizeof(int32_t), st));
+  HIPCHK(hipMemsetAsync(F.disc_flags, 0, 4 * sizeof(int32_t), st));
+  for (int l = 0; l < S.nlevels; ++l) {            // children before parents: the levels of the factorization plan
+    const int cnt = S.lvlptr[l + 1] - S.lvlptr[l];
+    const int nw = F.disc_lvl_wide[l], nv = cnt - nw;
+    if (nv > 0)
+      hipLaunchKernelGGL(k_front_discover, dim3((nv + 3) / 4), dim3(256), size_t(4) * 64 * DISC_LD * 8, st,
+                         static_cast<const DiscTask*>(F.disc_tasks), F.disc_list + S.lvlptr[l], nv, F.clist, F.cmap, F.invp,
+                         F.asrc, F.disc_arc, d_val, F.disc_arena, F.disc_ddelay, F.disc_dvar, F.disc_pseq, F.disc_ptwo,
+                         F.disc_pcnt, F.disc_flags, small, u, nn);
+    if (nw > 0)
+      hipLaunchKernelGGL(k_front_discover_wg, dim3(nw), dim3(256), 0, st,
+                         static_cast<const DiscTask*>(F.disc_tasks), F.disc_list + S.lvlptr[l] + nv, nw, F.clist, F.cmap,
+                         F.invp, F.asrc, F.disc_arc, d_val, F.disc_arena, F.disc_scratch, F.disc_ddelay, F.disc_dvar,
+                         F.disc_pseq, F.disc_ptwo, F.disc_pcnt, F.disc_flags, small, u, nn);
+  }
+  HIPCHK(hipGetLastError());
+  int32_t fl[4];
+  HIPCHK(hipMemcpyAsync(fl, F.disc_flags, sizeof(fl), hipMemcpyDeviceToHost, st));
+  std::vector<int32_t> pc(nn);
+  HIPCHK(hipMemcpyAsync(pc.data(), F.disc_pcnt, size_t(nn) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (fl[0] != 0) {                                // a front beyond its capacity / too many delays: not applicable
+    if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] discovery: overflow (flags %d: 1 = a front beyond its row capacity with its delays, 2 = too many delays out of a front)\n", fl[0]);
+    return hipSuccess;
+  }
+  int64_t tot = 0;
+  for (int s = 0; s < nn; ++s) tot += pc[s];
+  if (tot != n) return hipSuccess;                 // (cannot happen without the overflow flag; never trust it blindly)
+  std::vector<int32_t> ps(size_t(F.disc_pcap));
+  std::vector<uint8_t> pt(size_t(F.disc_pcap));
+  HIPCHK(hipMemcpy(ps.data(), F.disc_pseq, ps.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(pt.data(), F.disc_ptwo, pt.size(), hipMemcpyDeviceToHost));
+  seq.resize(n);
+  two.assign(n, 0);
+  std::vector<char> seen(n, 0);
+  int64_t k = 0;
+  for (int s = 0; s < nn; ++s) {                   // supernodes are numbered in postorder: children first
+    const int64_t po = F.disc_host[2 * s];
+    if (pc[s] > F.disc_host[2 * s + 1]) return hipSuccess;
+    for (int j = 0; j < pc[s]; ++j) {
+      const int v = ps[size_t(po + j)];
+      if (v < 0 || v >= n || seen[v]) return hipSuccess;
+      seen[v] = 1;
+      seq[k] = v;
+      two[k] = pt[size_t(po + j)];
+      ++k;
+    }
+  }
+  ndelayed = fl[1];
+  status = 0;
+  return hipSuccess;
 }
 
 hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const double* d_val,

@@ -151,6 +151,16 @@ struct DeviceFactor {
   // tasks and the element ranges of their images / gather lists
   int wtail_k0 = -1, wtail_tbeg = 0, wtail_tcnt = 0;
   int64_t wtail_lf0 = 0, wtail_lb0 = 0, wtail_gp0 = 0, wtail_gp1 = 0, wtail_gs0 = 0, wtail_gs1 = 0;
+  // pivot-order discovery (k_front_discover): built on first use, freed with the rest
+  void* disc_tasks = nullptr;
+  uint32_t* disc_arc = nullptr;
+  int32_t *disc_ddelay = nullptr, *disc_dvar = nullptr, *disc_pseq = nullptr, *disc_pcnt = nullptr, *disc_flags = nullptr;
+  uint8_t* disc_ptwo = nullptr;
+  double *disc_arena = nullptr, *disc_scratch = nullptr;
+  int32_t* disc_list = nullptr;             // per level: wave fronts, then workgroup fronts
+  std::vector<int> disc_lvl_wide;           // ... how many of the latter
+  std::vector<int64_t> disc_host;           // (poff, mcap) per front
+  int64_t disc_pcap = 0;
   int wimg_units = 64;            // LDS staging area per wave of the wide backward launches (16-byte units)
   int32_t* wpull2 = nullptr;      // dense form of the gather lists for fronts with at most two sources per row
   std::vector<int> wstage_unit;   // per stage: first task if every run is one front in task order, else -1
@@ -214,6 +224,11 @@ void dev_free_coo(DeviceFactor& F);
 hipError_t dev_vec_add(int n, double* d_x, const double* d_r, hipStream_t st);
 hipError_t dev_max_abs(int n, const double* d_v, unsigned long long* d_out, hipStream_t st);
 hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
+// the elimination sequence threshold partial pivoting WITH run-time delays finds for these values (gsls_device.hip,
+// "PIVOT-ORDER DISCOVERY"): seq[k] = variable of the k-th pivot, two[k] = 1 on the first column of a 2x2 pivot;
+// status 0 = found, 1 = not applicable here (a front beyond a wavefront, too many delays), the arrays are then unset
+hipError_t dev_discover(const Symbolic& S, DeviceFactor& F, const double* d_val, double small, double u, hipStream_t st,
+                        std::vector<int32_t>& seq, std::vector<uint8_t>& two, int& status, int& ndelayed);
 hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
                      int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);
