@@ -173,7 +173,9 @@ def facade_timings(prob, a, nemin):
                            "status": [rs["status_factorize"], rs["status_solve"]],
                            "max_err": float(np.abs(rs["sol"] - xs).max()),
                            "note": "SBLS_solve_explicit (src/sbls/sbls.f90:5073-5388) with its refinement loop handed to the backend "
-                                   "(integration/patch_sbls.py); K is assembled on the host"}
+                                   "(integration/patch_sbls.py); on refactorizations A%val, H%val, -C%val go to the "
+                                   "backend from the caller's arrays and K's values are put together in HBM "
+                                   "(gsls_set_value_part), and the solve runs in SOL"}
     except Exception as e:      # the facade run is a report, not the metric
         out["error"] = repr(e)[:200]
     return out

@@ -48,6 +48,7 @@ SIGNATURES = {
     "gsls_set_coo": (C.c_int, [C.c_void_p, i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsls_factor_coo": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),
                                   C.POINTER(Inform)]),
+    "gsls_set_value_part": (C.c_int, [C.c_void_p, i32, C.c_void_p, i64, f64]),
     "gsls_factor_coo_dev": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),
                                       C.POINTER(Inform)]),
     "gsls_residual": (C.c_int, [C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32, C.c_void_p, i32,

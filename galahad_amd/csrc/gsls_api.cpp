@@ -53,6 +53,11 @@ struct Handle {
   bool tpp_unflagged = false;     // the flags were dropped once after learning; if failures return they stay
   bool tpp_dirty = false;
   bool have_coo = false;          // gsls_set_coo has been called for the analysed pattern
+  // gsls_set_value_part: the next gsls_factor_coo takes the matrix values from up to four host arrays laid end to end
+  // (SBLS: K = [A-part | H-part | -C-part], sbls.f90:3319-3322) instead of one assembled array
+  struct ValuePart { const double* val = nullptr; int64_t len = 0; double mult = 1.0; };
+  ValuePart parts[4];
+  int nparts = 0;
   bool coo_uploaded = false;      // ... and its structure is on the device
   std::vector<int32_t> coo_row, coo_col, coo_map;
   int shard_repairs = 0;          // repair rounds of the sharded path (plan_repair's pass counter)
@@ -1083,6 +1088,7 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
 
 int gsls_factor(void* handle, int32_t posdef, const double* val, const double* scale,
                 const gsls_options* options, gsls_inform* inform) {
+  if (handle) (void)gsls_set_value_part(handle, -1, nullptr, 0, 1.0);   // (registered for a gsls_factor_coo that never came)
   return factor_common(static_cast<Handle*>(handle), posdef, val, scale, false, options, inform);
 }
 
@@ -1135,8 +1141,22 @@ static int factor_coo_common(Handle* h, int posdef, const double* val, const dou
     std::memset(inform, 0, sizeof(*inform));
     return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
   }
+  const int nparts = on_device ? 0 : h->nparts;
+  Handle::ValuePart parts[4];
+  for (int k = 0; k < 4; ++k) { parts[k] = h->parts[k]; h->parts[k] = Handle::ValuePart(); }
+  h->nparts = 0;                    // (a registration serves ONE factorization)
   if (h->S.n == 0) return factor_common(h, posdef, val, scale, on_device, options, inform);
-  if (!val) {
+  if (nparts > 0) {
+    int64_t tot = 0;
+    for (int k = 0; k < nparts; ++k) {
+      if (parts[k].len < 0 || (parts[k].len > 0 && !parts[k].val)) tot = -1;
+      if (tot >= 0) tot += parts[k].len;
+    }
+    if (tot != int64_t(h->coo_map.size())) {
+      *inform = h->last;
+      return inform->flag = GSLS_ERROR_VAL;
+    }
+  } else if (!val) {
     *inform = h->last;
     return inform->flag = GSLS_ERROR_VAL;
   }
@@ -1156,7 +1176,17 @@ static int factor_coo_common(Handle* h, int posdef, const double* val, const dou
     *inform = h->last;
     return fail_hip(h, inform, e);
   }
-  if (on_device) e = hipMemcpyAsync(h->F.coo_val, val, h->F.coo_ne * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+  if (nparts > 0) {
+    if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] factor_coo: values from %d registered parts\n", nparts);
+    int64_t off = 0;
+    for (int k = 0; k < nparts && e == hipSuccess; ++k) {
+      if (parts[k].len == 0) continue;
+      e = hipMemcpyAsync(h->F.coo_val + off, parts[k].val, size_t(parts[k].len) * sizeof(double), hipMemcpyHostToDevice,
+                         h->stream);
+      if (e == hipSuccess && parts[k].mult != 1.0) e = dev_scale_values(h->F.coo_val + off, parts[k].len, parts[k].mult, h->stream);
+      off += parts[k].len;
+    }
+  } else if (on_device) e = hipMemcpyAsync(h->F.coo_val, val, h->F.coo_ne * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
   else e = hipMemcpyAsync(h->F.coo_val, val, h->F.coo_ne * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = dev_map_values(h->F, h->F.coo_val, h->stream);
   if (e != hipSuccess) {
@@ -1167,6 +1197,22 @@ static int factor_coo_common(Handle* h, int posdef, const double* val, const dou
   // again after every re-analysis (dev_upload_symbolic frees and rebuilds the device arrays, F.scale included -- an
   // upload made here would be read back from freed memory by the first factorization of every pattern).
   return factor_common(h, posdef, h->F.valcsc, scale, true, options, inform, (scale && !on_device) ? 1 : -1);
+}
+
+int gsls_set_value_part(void* handle, int32_t part, const double* val, int64_t len, double mult) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return GSLS_ERROR_CALL_SEQUENCE;
+  if (part < 0) {                   // forget the registration
+    for (int k = 0; k < 4; ++k) h->parts[k] = Handle::ValuePart();
+    h->nparts = 0;
+    return GSLS_SUCCESS;
+  }
+  if (part >= 4 || len < 0 || (len > 0 && !val)) return GSLS_ERROR_VAL;
+  h->parts[part].val = val;
+  h->parts[part].len = len;
+  h->parts[part].mult = mult;
+  h->nparts = std::max(h->nparts, part + 1);
+  return GSLS_SUCCESS;
 }
 
 int gsls_factor_coo(void* handle, int32_t posdef, const double* val, const double* scale,

@@ -5498,6 +5498,17 @@ hipError_t dev_set_coo(DeviceFactor& F, int n, int64_t nzcsc, int64_t ne, const 
   return hipStreamSynchronize(st);
 }
 
+__global__ void k_scale_values(int64_t n, double* __restrict__ v, double mult) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) v[i] *= mult;
+}
+// a stretch of the caller's values times a constant (gsls_set_value_part: SBLS stores -C in K)
+hipError_t dev_scale_values(double* d_val, int64_t n, double mult, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scale_values, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, n, d_val, mult);
+  return hipGetLastError();
+}
+
 hipError_t dev_map_values(DeviceFactor& F, const double* d_val_in, hipStream_t st) {
   if (F.nscatter_coo > 0)
     hipLaunchKernelGGL(k_map_values, dim3(unsigned((F.nscatter_coo + 255) / 256)), dim3(256), 0, st, F.nscatter_coo,

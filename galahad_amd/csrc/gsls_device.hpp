@@ -217,6 +217,7 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
 hipError_t dev_set_coo(DeviceFactor& F, int n, int64_t nzcsc, int64_t ne, const int32_t* row, const int32_t* col,
                        const int32_t* map, hipStream_t st);
 hipError_t dev_map_values(DeviceFactor& F, const double* d_val_in, hipStream_t st);
+hipError_t dev_scale_values(double* d_val, int64_t n, double mult, hipStream_t st);
 hipError_t dev_residual(DeviceFactor& F, int n, int nrhs, const double* d_x, int ldx, const double* d_b, int ldb,
                         double* d_r, int ldr, hipStream_t st);
 void dev_free_coo(DeviceFactor& F);

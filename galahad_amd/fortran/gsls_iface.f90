@@ -23,7 +23,7 @@ module GALAHAD_GSLS_double
   public :: gsls_keep, gsls_options, gsls_inform
   public :: GSLS_initialize, GSLS_analyse, GSLS_factor, GSLS_solve, GSLS_solve_mult
   public :: GSLS_enquire_posdef, GSLS_enquire_indef, GSLS_alter, GSLS_free
-  public :: GSLS_set_coo, GSLS_factor_coo, GSLS_residual, GSLS_get_order, GSLS_solve_ir
+  public :: GSLS_set_coo, GSLS_factor_coo, GSLS_residual, GSLS_get_order, GSLS_solve_ir, GSLS_set_value_part
   ! one system over several GPUs, one process per GPU (include/gsls.h, "multi-GPU with the exchange INSIDE the library";
   ! what one ssids_factor / ssids_solve call does for several devices, src/ssids/fkeep.F90:99-174, 229-318)
   public :: GSLS_comm_unique_id, GSLS_comm_init, GSLS_comm_factor, GSLS_comm_solve, GSLS_comm_free
@@ -150,6 +150,14 @@ module GALAHAD_GSLS_double
       type(c_ptr), value :: scale
       type(gsls_options), intent(in) :: options
       type(gsls_inform), intent(out) :: inform
+    end function
+    integer(c_int) function c_gsls_set_value_part(handle, part, val, len, mult) bind(C, name='gsls_set_value_part')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: part
+      type(c_ptr), value :: val
+      integer(c_int64_t), value :: len
+      real(c_double), value :: mult
     end function
     integer(c_int) function c_gsls_residual(handle, nrhs, x, ldx, b, ldb, r, ldr, inform) &
         bind(C, name='gsls_residual')
@@ -386,6 +394,30 @@ contains
     if (present(scale)) sp = c_loc(scale)
     rc = c_gsls_factor_coo(keep%handle, merge(1_c_int32_t, 0_c_int32_t, posdef), val, sp, options, inform)
   end subroutine GSLS_factor_coo
+
+  ! The next GSLS_factor_coo reads its values from the registered arrays laid end to end (part = 0, 1, 2 ...), each times
+  ! mult, instead of from its val argument: SBLS's K%val = [ A%val | H%val | -C%val ] without the host copy
+  ! (sbls.f90:3349, 3404, 3967).  The arrays are read when GSLS_factor_coo runs, so they must be the caller's own storage
+  ! (contiguous: no temporary), alive until then.  Without val: forget every registration.
+  subroutine GSLS_set_value_part(keep, part, val, mult)
+    type(gsls_keep), intent(inout) :: keep
+    integer, intent(in) :: part
+    real(wp), optional, contiguous, target, intent(in) :: val(:)
+    real(wp), optional, intent(in) :: mult
+    integer(c_int) :: rc
+    real(c_double) :: f
+    if (.not. present(val)) then
+      rc = c_gsls_set_value_part(keep%handle, -1_c_int32_t, c_null_ptr, 0_c_int64_t, 1.0_c_double)
+      return
+    end if
+    f = 1.0_c_double
+    if (present(mult)) f = mult
+    if (size(val) > 0) then
+      rc = c_gsls_set_value_part(keep%handle, int(part, c_int32_t), c_loc(val), int(size(val), c_int64_t), f)
+    else
+      rc = c_gsls_set_value_part(keep%handle, int(part, c_int32_t), c_null_ptr, 0_c_int64_t, f)
+    end if
+  end subroutine GSLS_set_value_part
 
   ! r = b - A x with the matrix of the last GSLS_factor_coo (the residual step of SLS_solve_ir, sls.f90:4826-4934)
   subroutine GSLS_residual(x, b, r, keep, inform)

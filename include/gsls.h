@@ -171,6 +171,14 @@ int gsls_factor_coo(void* handle, int32_t posdef, const double* val, const doubl
 int gsls_factor_coo_dev(void* handle, int32_t posdef, const double* d_val, const double* d_scale,
                         const gsls_options* options, gsls_inform* inform);
 
+/* The values of the NEXT gsls_factor_coo come from up to four host arrays laid end to end (part 0 first), each times
+ * `mult`, instead of from its `val` argument (which may then be NULL): what SBLS_form_n_factorize_explicit assembles on
+ * the host as K%val = [ A%val | H%val | -C%val ] (sbls.f90:3319-3322, 3349, 3404, 3967) is assembled in HBM, the three
+ * arrays going over the link straight from where the caller keeps them.  The lengths must add up to the `ne` of
+ * gsls_set_coo (else gsls_factor_coo returns GSLS_ERROR_VAL); the arrays must stay valid until that call returns; a
+ * registration serves one factorization.  part < 0 forgets a registration. */
+int gsls_set_value_part(void* handle, int32_t part, const double* val, int64_t len, double mult);
+
 /* r = b - A x for nrhs vectors (host memory, column-major), A = the matrix of the last gsls_factor_coo
  * (the residual step of SLS_solve_ir, sls.f90:4826-4934).  Row by row in a fixed order: reproducible. */
 int gsls_residual(void* handle, int32_t nrhs, const double* x, int32_t ldx, const double* b, int32_t ldb,

@@ -260,6 +260,55 @@ COPY_ROUTINES = """
      RETURN
      END SUBROUTINE SLS_copy_control_to_gsls
 
+!-*-*-*-*-   S L S _ G S L S _ V A L U E _ P A R T  S U B R O U T I N E  -*-*-*-*-
+
+     SUBROUTINE SLS_gsls_value_part( data, part, VAL, mult )
+
+!  (gsls only; used by SBLS) the next SLS_factorize takes the values of the matrix from the registered arrays laid end
+!  to end (part = 0, 1, 2), each times mult, instead of from matrix%val: gsls_set_value_part, include/gsls.h.
+!  Without VAL: forget every registration.  The arrays are read when SLS_factorize runs
+
+     TYPE ( SLS_data_type ), INTENT( INOUT ) :: data
+     INTEGER, INTENT( IN ) :: part
+     REAL ( KIND = wp ), INTENT( IN ), OPTIONAL, CONTIGUOUS, TARGET,            &
+                                       DIMENSION( : ) :: VAL
+     REAL ( KIND = wp ), INTENT( IN ), OPTIONAL :: mult
+
+     IF ( .NOT. SLS_gsls_parts_ok( data ) ) RETURN
+     CALL GSLS_set_value_part( data%gsls_keep, part, VAL, mult )
+     RETURN
+     END SUBROUTINE SLS_gsls_value_part
+
+!-*-*-*-*-*-   S L S _ G S L S _ P A R T S _ O K   F U N C T I O N  -*-*-*-*-*-
+
+     FUNCTION SLS_gsls_parts_ok( data )
+
+!  is this an analysed gsls factorization whose values go to the backend in the caller's storage order?
+
+     LOGICAL :: SLS_gsls_parts_ok
+     TYPE ( SLS_data_type ), INTENT( IN ) :: data
+
+     SLS_gsls_parts_ok = .FALSE.
+     IF ( data%len_solver /= 4 ) RETURN
+     IF ( data%solver( 1 : 4 ) /= 'gsls' ) RETURN
+     SLS_gsls_parts_ok = .NOT. data%explicit_scaling
+     RETURN
+     END FUNCTION SLS_gsls_parts_ok
+
+!-*-*-*-*-*-   S L S _ G S L S _ R E S I D U A L  S U B R O U T I N E  -*-*-*-*-*-
+
+     SUBROUTINE SLS_gsls_residual( data, X, B, R )
+
+!  (gsls only; used by SBLS) R = B - A X with the matrix of the last SLS_factorize, on the device
+
+     TYPE ( SLS_data_type ), INTENT( INOUT ) :: data
+     REAL ( KIND = wp ), INTENT( IN ), DIMENSION( : ) :: X, B
+     REAL ( KIND = wp ), INTENT( OUT ), DIMENSION( : ) :: R
+
+     CALL GSLS_residual( X, B, R, data%gsls_keep, data%gsls_inform )
+     RETURN
+     END SUBROUTINE SLS_gsls_residual
+
 !-*-   S L S _ C O P Y _ I N F O R M _ F R O M _ G S L S  S U B R O U T I N E  -*-
 
      SUBROUTINE SLS_copy_inform_from_gsls( inform, info_gsls )
@@ -313,6 +362,7 @@ def main(src, dst):
     shared = refine = scatter = 0
     refine_done = False
     mc68_done = False
+    public_done = False
     for ln in lines:
         if re.fullmatch(r"\s*CASE \( 'ssids' \)", ln) and k < len(ARMS):
             out.extend(ARMS[k].rstrip("\n").split("\n"))
@@ -352,6 +402,9 @@ def main(src, dst):
             out.insert(len(out) - 1, "     CASE ( 'gsls' )")
             out.insert(len(out) - 1, "       mc6168_ordering = .FALSE.")
             mc68_done = True
+        if ln.strip().startswith("PUBLIC :: SLS_initialize, SLS_analyse, SLS_factorize, SLS_solve,") and not public_done:
+            out.append("     PUBLIC :: SLS_gsls_value_part, SLS_gsls_parts_ok, SLS_gsls_residual")
+            public_done = True
         out.append(ln)
         if ln.strip() == "USE SPRAL_SSIDS":
             out.append("     USE GALAHAD_GSLS_double")
@@ -364,7 +417,8 @@ def main(src, dst):
         if ln.strip() == "END SUBROUTINE SLS_copy_inform_from_ssids":
             out.extend(COPY_ROUTINES.split("\n"))
     assert k == len(ARMS), "expected %d ssids arms, patched %d" % (len(ARMS), k)
-    assert shared == 2 and refine_done and scatter == 2 and mc68_done, (shared, refine, refine_done, scatter, mc68_done)
+    assert shared == 2 and refine_done and scatter == 2 and mc68_done and public_done, \
+        (shared, refine, refine_done, scatter, mc68_done, public_done)
     text = "\n".join(out)
     assert "USE GALAHAD_GSLS_double" in text and "TYPE ( gsls_keep ) :: gsls_keep" in text
     open(dst, "w").write(text)

@@ -141,7 +141,7 @@ def sbls_available(dropin=False):
 
 
 def run_sbls(n, m, H, A, Cm, rhs, *, solver="gsls", factorization=2, repeat=1, itref_max=1,
-             threads=None, timeout=3600, print_level=0):
+             threads=None, timeout=3600, print_level=0, drift=False, get_norm_residual=False):
     """SBLS_form_and_factorize + SBLS_solve on K = [H A^T; A -C].  H, A, Cm = (row, col, val) with
     1-based indices (H, C lower triangles).  Returns dict(status_factorize, status_solve, sol, ...)."""
     exe = SBLS_DROPIN if solver == "gsls" else SBLS_DRIVER
@@ -152,7 +152,8 @@ def run_sbls(n, m, H, A, Cm, rhs, *, solver="gsls", factorization=2, repeat=1, i
         with open(pin, "wb") as f:
             f.write(struct.pack("<2i", 1396853330, 1))
             f.write(struct.pack("<10i", n, m, len(H[0]), len(A[0]), len(Cm[0]), SOLVERS[solver],
-                                factorization, repeat, itref_max, print_level))
+                                factorization, repeat, itref_max,
+                                print_level + (100 if drift else 0) + (1000 if get_norm_residual else 0)))
             for (r, c, v) in (H, A, Cm):
                 f.write(np.ascontiguousarray(r, dtype=np.int32).tobytes())
                 f.write(np.ascontiguousarray(c, dtype=np.int32).tobytes())
@@ -168,11 +169,15 @@ def run_sbls(n, m, H, A, Cm, rhs, *, solver="gsls", factorization=2, repeat=1, i
             raise RuntimeError("sbls driver failed rc=%d\n%s\n%s" % (p.returncode, p.stdout, p.stderr))
         if print_level:
             print(p.stdout)
+        if os.environ.get("GSLS_DEBUG"):
+            print(p.stderr[-20000:])
         buf = open(pout, "rb").read()
         ints = np.frombuffer(buf, dtype="<i4", count=6)
         tms = np.frombuffer(buf, dtype="<f8", count=4, offset=24)
         sol = np.frombuffer(buf, dtype="<f8", count=n + m, offset=24 + 32).copy()
-        return dict(status_factorize=int(ints[0]), status_solve=int(ints[1]), factorization=int(ints[2]),
+        nres = float(np.frombuffer(buf, dtype="<f8", count=1, offset=24 + 32 + 8 * (n + m))[0]) \
+            if len(buf) >= 24 + 32 + 8 * (n + m + 1) else None
+        return dict(norm_residual=nres, status_factorize=int(ints[0]), status_solve=int(ints[1]), factorization=int(ints[2]),
                     rank=int(ints[3]), negative_eigenvalues=int(ints[4]), t_factorize=float(tms[0]),
                     t_solve=float(tms[1]), t_factorize_median=float(tms[2]), t_solve_median=float(tms[3]),
                     sol=sol)

@@ -9,9 +9,12 @@
 !              int32 n m h_ne a_ne c_ne solver(0 ssids, 1 sytr, 4 gsls) factorization repeat itref_max spare
 !              int32 Hrow Hcol ; real64 Hval ; int32 Arow Acol ; real64 Aval ; int32 Crow Ccol ;
 !              real64 Cval ; real64 rhs(n+m)
+!              spare = SBLS print level + 100 * drift + 1000 * get_norm_residual.  drift = 1: round k > 1 factorizes
+!              H * (1 + (k-1)/4), C * (1 + (k-1)/2) and, on odd k only (new_a = 0 on even k), A * (1 - (k-1)/10): the
+!              values change in the CALLER's arrays between factorizations, as in an interior-point loop
 ! result.bin : int32 status_factorize status_solve factorization_used rank negative_eigenvalues spare
 !              real64 t_factorize_best t_solve_best t_factorize_median t_solve_median
-!              real64 sol(n+m)
+!              real64 sol(n+m) ; real64 norm_residual (inform%norm_residual of the last solve)
 program gsls_sbls_driver
   use GALAHAD_SBLS_double
   implicit none
@@ -22,8 +25,8 @@ program gsls_sbls_driver
   type(SBLS_inform_type) :: inform
   character(len=1024) :: fin, fout
   integer :: magic, version, n, m, h_ne, a_ne, c_ne, isolver, factorization, repeat, itref, spare
-  real(wp), allocatable :: rhs(:), sol(:), tf(:), ts(:)
-  integer :: s, u, k, st_f, st_s
+  real(wp), allocatable :: rhs(:), sol(:), tf(:), ts(:), Hv0(:), Av0(:), Cv0(:)
+  integer :: s, u, k, st_f, st_s, drift, getnorm
   integer(long) :: c0, c1, crate
 
   call get_command_argument(1, fin)
@@ -48,8 +51,11 @@ program gsls_sbls_driver
   control%preconditioner = 2
   control%factorization = factorization
   control%itref_max = itref
-  control%get_norm_residual = .false.
-  control%print_level = spare      ! header's last int: SBLS print level (debugging aid)
+  getnorm = spare / 1000 ; drift = mod(spare, 1000) / 100 ; spare = mod(spare, 100)
+  control%get_norm_residual = getnorm /= 0
+  control%print_level = spare      ! SBLS print level (debugging aid)
+  allocate(Hv0(h_ne), Av0(a_ne), Cv0(c_ne))
+  Hv0 = H%val ; Av0 = A%val ; Cv0 = C%val
   if (isolver == 4) then
     control%symmetric_linear_solver = 'gsls'
     control%definite_linear_solver = 'gsls'
@@ -67,6 +73,15 @@ program gsls_sbls_driver
   do k = 1, repeat
     if (k > 1) then      ! same structure, new values: what an interior-point iteration does
       control%new_a = 1 ; control%new_h = 1 ; control%new_c = 1
+      if (drift /= 0) then
+        H%val = Hv0 * (1.0_wp + 0.25_wp * real(k - 1, wp))
+        C%val = Cv0 * (1.0_wp + 0.5_wp * real(k - 1, wp))
+        if (mod(k, 2) == 1) then
+          A%val = Av0 * (1.0_wp - 0.1_wp * real(k - 1, wp))
+        else
+          control%new_a = 0
+        end if
+      end if
     end if
     call system_clock(c0)
     call SBLS_form_and_factorize(n, m, H, A, C, data, control, inform)
@@ -86,6 +101,7 @@ program gsls_sbls_driver
   write(u) st_f, st_s, inform%factorization, inform%rank, inform%SLS_inform%negative_eigenvalues, 0
   write(u) minval(tf), minval(ts), median(tf), median(ts)
   write(u) sol
+  write(u) inform%norm_residual
   close(u)
   call SBLS_terminate(data, control, inform)
 

@@ -18,18 +18,36 @@ def _changed(a, b):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "sbls", "sbls.f90")), reason="reference tree not present")
 def test_patch_sbls_edits_only_the_refinement_loop_of_solve_explicit():
+    """...and, since round 3, the three value copies of SBLS_form_n_factorize_explicit plus the in-place solve (f1)."""
     import patch_sbls
     src = open(os.path.join(REF, "sbls", "sbls.f90")).read()
     out = patch_sbls.patch(src)
     lines = src.split("\n")
-    beg = next(k for k, ln in enumerate(lines) if ln.strip().startswith("SUBROUTINE SBLS_solve_explicit("))
-    end = next(k for k, ln in enumerate(lines) if ln.strip().startswith("END SUBROUTINE SBLS_solve_explicit"))
+
+    def span(name):
+        b = next(k for k, ln in enumerate(lines) if ln.strip().startswith("SUBROUTINE %s(" % name))
+        e = next(k for k, ln in enumerate(lines) if ln.strip().startswith("END SUBROUTINE %s" % name))
+        return b, e
+    beg, end = span("SBLS_solve_explicit")
+    fbeg, fend = span("SBLS_form_n_factorize_explicit")
     ops = _changed(src, out)
-    assert len(ops) == 4, ops                                    # declaration, loop header, control argument, residual test
-    assert all(beg < op[1] and op[2] <= end for op in ops), ops  # all inside SBLS_solve_explicit (sbls.f90:5073-5388)
-    assert out.count("K_control_ir") == 6 and out.count("itref_loop") == 5
+    in_solve = [op for op in ops if beg < op[1] and op[2] <= end]
+    in_form = [op for op in ops if fbeg < op[1] and op[2] <= fend]
+    other = [op for op in ops if op not in in_solve and op not in in_form]
+    assert len(in_solve) == 5, in_solve   # declaration, in-place arm, loop header, control argument, residual test
+    assert len(in_form) == 5, in_form     # declaration, decision + registration, the copies of A%val, H%val, -C%val
+    assert len(other) == 1 and "gsls_stale" in "\n".join(out.split("\n")[other[0][3]:other[0][4]]), other
+    # no statement of the reference is lost: replaced lines are the three IF headers that gained ".NOT. gsls_parts" and the
+    # four of the refinement loop
+    removed = [ln.strip() for tag, i1, i2, j1, j2 in ops if tag in ("delete", "replace") for ln in lines[i1:i2] if ln.strip()]
+    assert len(removed) <= 8, removed
+    assert out.count("K_control_ir") == 11 and out.count("itref_loop") == 5
     assert "DO iter = 0, itref_loop" in out and out.count("DO iter = 0, control%itref_max") == \
         src.count("DO iter = 0, control%itref_max") - 1       # the other solve routines keep their loops
+    # the host copies are skipped only behind the flag, and a stale K%val is refreshed on the reference's path
+    assert out.count(".NOT. gsls_parts") == 3
+    assert "new_a = MAX( new_a, 1 ) ; new_h = MAX( new_h, 1 )" in out and "efactors%gsls_stale = .TRUE." in out
+    assert "CALL SLS_gsls_value_part( efactors%K_data, - 1 )" in out
     # applying it twice must fail loudly, not produce a half-patched file
     with pytest.raises(SystemExit):
         patch_sbls.patch(out)

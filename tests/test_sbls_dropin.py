@@ -118,6 +118,44 @@ def test_sbls_refinement_runs_in_the_backend():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("repeat", [1, 2, 3, 4])
+def test_sbls_values_assembled_on_the_device(repeat):
+    """on a refactorization (same structure) the patched SBLS_form_n_factorize_explicit does not copy A%val,
+    H%val, -C%val into K%val (sbls.f90:3349, 3404, 3967) -- the backend takes the three arrays where they are
+    (gsls_set_value_part) and K's values are put together in HBM.  The driver CHANGES the caller's arrays between rounds
+    (H, C every round; A on odd rounds only, new_a = 0 on even ones), so a stale or misplaced part shows in the solution
+    of the last round; C /= 0 checks the sign.  get_norm_residual: the backend's b - K x (gsls_residual) instead of the
+    host loops over K%val (sbls.f90:5343-5372), which is stale here."""
+    refio = _need()
+    n, m = 3000, 900
+    H, A, _ = _qp_kkt(n, m, 31)
+    j = np.arange(1, m + 1)
+    C = (j.astype(np.int32), j.astype(np.int32), np.linspace(0.5, 2.0, m))      # K = [H A^T; A -C]
+    rng = np.random.default_rng(13)
+    rhs = rng.uniform(-1, 1, n + m)
+    r = refio.run_sbls(n, m, H, A, C, rhs, solver="gsls", factorization=2, repeat=repeat, itref_max=1, drift=True,
+                       get_norm_residual=True)
+    assert (r["status_factorize"], r["status_solve"]) == (0, 0)
+    k = repeat
+    ka = k if k % 2 == 1 else k - 1                       # A last changed on the last odd round
+    Hv = H[2] * (1.0 + 0.25 * (k - 1))
+    Cv = C[2] * (1.0 + 0.5 * (k - 1))
+    Av = A[2] * (1.0 - 0.1 * (ka - 1))
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    Hm = sp.coo_matrix((Hv, (H[0] - 1, H[1] - 1)), shape=(n, n)).tocsr()
+    Hm = Hm + sp.tril(Hm, -1).T
+    Am = sp.coo_matrix((Av, (A[0] - 1, A[1] - 1)), shape=(m, n)).tocsr()
+    Cm = sp.diags(Cv)
+    K = sp.bmat([[Hm, Am.T], [Am, -Cm]]).tocsc()
+    ref = spl.spsolve(K, rhs)
+    assert np.abs(r["sol"] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    true_res = np.abs(rhs - K @ r["sol"]).max()
+    assert r["norm_residual"] is not None and r["norm_residual"] <= 1e-10
+    assert abs(r["norm_residual"] - true_res) <= 1e-11
+
+
+@pytest.mark.gpu
 def test_sbls_cfg3_full_size():
     """BASELINE.json configs[2]: SBLS KKT saddle point of a synthetic QP, n = 1e6, m = 2e5, through the
     real SBLS; three form_and_factorize + solve rounds (new values, same structure) as CQP would do."""
