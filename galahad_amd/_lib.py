@@ -41,6 +41,8 @@ SIGNATURES = {
     "gsls_destroy": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gsls_analyse": (C.c_int, [C.c_void_p, i32, p_i64, p_i32, p_i32, C.POINTER(Options),
                                C.POINTER(Inform)]),
+    "gsls_analyse_matching": (C.c_int, [C.c_void_p, i32, p_i64, p_i32, C.c_void_p, p_i32, C.POINTER(Options),
+                                        C.POINTER(Inform)]),
     "gsls_factor": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),
                               C.POINTER(Inform)]),
     "gsls_factor_dev": (C.c_int, [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.POINTER(Options),

@@ -52,6 +52,8 @@ struct Handle {
   std::vector<int32_t> partner;   // per variable: the variable it was paired with by the pre-ordering, or -1
   bool tpp_unflagged = false;     // the flags were dropped once after learning; if failures return they stay
   bool tpp_dirty = false;
+  bool keep_match_scale = false;     // (gsls_analyse called from gsls_analyse_matching)
+  std::vector<double> match_scale;   // scaling saved by gsls_analyse_matching for factorizations with options.scaling = 3
   bool have_coo = false;          // gsls_set_coo has been called for the analysed pattern
   // gsls_set_value_part: the next gsls_factor_coo takes the matrix values from up to four host arrays laid end to end
   // (SBLS: K = [A-part | H-part | -C-part], sbls.f90:3319-3322) instead of one assembled array
@@ -324,6 +326,7 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
   const double t0 = now();
   h->analysed = h->factored = h->dev_ready = false;
   h->have_coo = h->coo_uploaded = false;
+  if (!h->keep_match_scale) h->match_scale.clear();
   h->learned = 0;
   h->shard_fast = h->shard_fast_off = false;
   h->tiny_ready = false;
@@ -657,12 +660,13 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   // ---- the reference's internal scalings (ssids.f90:921-1030), computed on the host from these values ------------
   std::vector<double> own_scale;
   if (!scale && options->scaling > 0) {
-    if (options->scaling == 3) return inform->flag = GSLS_ERROR_NO_SAVED_SCALING;   // needs the matching-based ordering
+    if (options->scaling == 3 && int(h->match_scale.size()) != S.n)
+      return inform->flag = GSLS_ERROR_NO_SAVED_SCALING;       // needs gsls_analyse_matching (ssids.f90:991-994)
     const int n = S.n;
     const int64_t nzv = h->ptr[n] - 1;
     std::vector<double> hv;
     const double* v = val;
-    if (on_device) {
+    if (on_device && options->scaling != 3) {
       hv.resize(size_t(nzv));
       e = hipMemcpyAsync(hv.data(), val, size_t(nzv) * sizeof(double), hipMemcpyDeviceToHost, h->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(h->stream);    // (the value map of gsls_factor_coo runs on this stream)
@@ -676,7 +680,8 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     own_scale.resize(n);
     int sf = 0;
     try {
-      if (options->scaling == 1) sf = hungarian_scale_sym(n, p0.data(), r0.data(), v, options->action != 0, own_scale.data());
+      if (options->scaling == 3) own_scale = h->match_scale;     // saved by the matching-based ordering
+      else if (options->scaling == 1) sf = hungarian_scale_sym(n, p0.data(), r0.data(), v, options->action != 0, own_scale.data());
       else if (options->scaling == 2) sf = auction_scale_sym(n, p0.data(), r0.data(), v, own_scale.data());
       else sf = equilib_scale_sym(n, p0.data(), r0.data(), v, own_scale.data());
     } catch (const std::bad_alloc&) {
@@ -1082,6 +1087,57 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   }
   h->factored = true;
   inform->time_factor = now() - t0;
+  h->last = *inform;
+  return inform->flag;
+}
+
+// ssids_analyse with values and options%ordering = 2 (ssids.f90:305-320 -> match_order_metis, spral/match_order.f90)
+int gsls_analyse_matching(void* handle, int32_t n, const int64_t* ptr, const int32_t* row, const double* val,
+                          int32_t* order, const gsls_options* options, gsls_inform* inform) {
+  gsls_inform local;
+  if (!inform) inform = &local;
+  std::memset(inform, 0, sizeof(*inform));
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return inform->flag = GSLS_ERROR_CALL_SEQUENCE;
+  gsls_options o;
+  if (options) o = *options; else gsls_default_options(&o);
+  if (n < 0) return inform->flag = GSLS_ERROR_A_N_OOR;
+  if (n > 0 && (!ptr || !row)) return inform->flag = GSLS_ERROR_A_PTR;
+  if (n > 0 && !val) return inform->flag = GSLS_ERROR_VAL;           // (ssids.f90:306-310: ordering 2 needs val)
+  if (n > 0 && !order) return inform->flag = GSLS_ERROR_ORDER;
+  if (n > 0 && ptr[0] != 1) return inform->flag = GSLS_ERROR_A_PTR;
+  for (int j = 0; j < n; ++j)
+    if (ptr[j + 1] < ptr[j]) return inform->flag = GSLS_ERROR_A_PTR;
+  if (o.ordering == GSLS_ORDER_USER) o.ordering = GSLS_ORDER_ND;     // (the compressed graph has no user order)
+  if (o.ordering < 0 || o.ordering > 3) return inform->flag = GSLS_ERROR_ORDER;
+  int sf = 0, npairs = 0;
+  std::vector<double> scaling(std::max(n, 1), 1.0);
+  if (n > 0) {
+    const int64_t nz = ptr[n] - 1;
+    for (int64_t k = 0; k < nz; ++k)
+      if (row[k] < 1 || row[k] > n) return inform->flag = GSLS_ERROR_A_ALL_OOR;
+    try {
+      // lower triangle by columns, 0-based, duplicates and upper-triangle entries as the analysis treats them: entries
+      // above the diagonal are mirrored (the matching works on |a_ij| of the symmetric matrix)
+      std::vector<int64_t> p0(n + 1);
+      std::vector<int32_t> r0(static_cast<size_t>(nz));
+      for (int j = 0; j <= n; ++j) p0[j] = ptr[j] - 1;
+      for (int64_t k = 0; k < nz; ++k) r0[k] = row[k] - 1;
+      sf = match_order_sym(n, p0.data(), r0.data(), val, o.ordering, order, scaling.data(), &npairs);
+    } catch (const std::bad_alloc&) {
+      return inform->flag = GSLS_ERROR_ALLOCATION;
+    }
+  }
+  o.ordering = GSLS_ORDER_USER;
+  h->keep_match_scale = true;
+  const int flag = gsls_analyse(handle, n, ptr, row, order, &o, inform);
+  h->keep_match_scale = false;
+  if (flag < 0) { h->match_scale.clear(); return flag; }
+  scaling.resize(n);
+  h->match_scale.swap(scaling);
+  if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] matching-based ordering: %d of %d variables in 2x2 pairs%s\n", 2 * npairs, n,
+                                    sf == 1 ? " (structurally singular)" : "");
+  if (sf == 1 && inform->flag == GSLS_SUCCESS) inform->flag = GSLS_WARNING_ANAL_SINGULAR;
   h->last = *inform;
   return inform->flag;
 }

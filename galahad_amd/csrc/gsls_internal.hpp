@@ -77,6 +77,9 @@ void shard_layout(Symbolic& S, int rank);    // per-rank factor / arena offsets 
 int hungarian_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, bool scale_if_singular,
                         double* scaling);
 int auction_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, double* scaling);
+// matching-based ordering + its scaling (SSIDS ordering = 2, spral/match_order.f90); order[i] = position, 1-based
+int match_order_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, int ordering, int32_t* order,
+                    double* scaling, int32_t* npairs);
 int equilib_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, double* scaling);
 
 void layout_contrib(Symbolic& S, bool reuse);

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <numeric>
 #include <queue>
 #include <vector>
 
@@ -173,8 +174,18 @@ int min_sum_matching(int n, const std::vector<int64_t>& ptr, const std::vector<i
 }  // namespace
 
 // ptr/row/val: lower triangle by columns, 0-based.  Returns 0, 1 (singular, scaled anyway) or -2 (singular, identity).
+static int hungarian_core(int n, const int64_t* ptr, const int32_t* row, const double* val, bool scale_if_singular,
+                          double* scaling, std::vector<int32_t>* match_out);
+
 int hungarian_scale_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, bool scale_if_singular,
                         double* scaling) {
+  return hungarian_core(n, ptr, row, val, scale_if_singular, scaling, nullptr);
+}
+
+// match_out (optional): the matching the scaling comes from, match[i] = the column matched to row i, -1 for the rows a
+// structurally singular matrix leaves out (then the matching of the non-singular part)
+static int hungarian_core(int n, const int64_t* ptr, const int32_t* row, const double* val, bool scale_if_singular,
+                          double* scaling, std::vector<int32_t>* match_out) {
   FullMatrix A = expand_log(n, ptr, row, val);
   std::vector<double> cmax(n, 0.0);
   for (int j = 0; j < n; ++j) {
@@ -189,10 +200,12 @@ int hungarian_scale_sym(int n, const int64_t* ptr, const int32_t* row, const dou
   const int matched = min_sum_matching(n, A.ptr, A.row, A.val, match, u, v);
   if (matched == n) {
     for (int i = 0; i < n; ++i) scaling[i] = std::exp((u[i] + v[i] - cmax[i]) / 2);
+    if (match_out) *match_out = match;
     return 0;
   }
   if (!scale_if_singular) {
     for (int i = 0; i < n; ++i) scaling[i] = 1.0;
+    if (match_out) *match_out = match;
     return -2;
   }
   // structurally singular: the variables whose row is unmatched leave (row and column); the rest is matched again
@@ -217,6 +230,11 @@ int hungarian_scale_sym(int n, const int64_t* ptr, const int32_t* row, const dou
   std::vector<int32_t> m2;
   std::vector<double> u2, v2;
   (void)min_sum_matching(nn, B.ptr, B.row, B.val, m2, u2, v2);
+  if (match_out) {
+    match_out->assign(n, -1);
+    for (int in = 0; in < nn; ++in)
+      if (m2[in] >= 0) (*match_out)[n2o[in]] = n2o[m2[in]];
+  }
   const double NONE = -RINF;
   std::vector<double> rs(n, NONE);
   for (int i = 0; i < n; ++i)
@@ -237,6 +255,103 @@ int hungarian_scale_sym(int n, const int64_t* ptr, const int32_t* row, const dou
   }
   for (int i = 0; i < n; ++i) scaling[i] = std::exp(rs[i]);
   return 1;
+}
+
+// Matching-based ordering (SSIDS ordering = 2: match_order_metis, src/spral/match_order.f90:51-208, after Duff & Pralet;
+// reached from ssids_analyse when the caller passes the values, ssids.f90:305-320).  The maximum-product matching of the
+// scaling pairs every variable with the column that holds "its" large entry; a matched pair (i, j), i /= j, is a 2x2 pivot
+// [a_ii a_ij; a_ij a_jj] that threshold pivoting will accept, PROVIDED i and j are neighbours in the elimination order.
+// So:  1. matching + scaling (hungarian_core);
+//      2. the cycles of the matching permutation are cut into pairs and singletons: walking a cycle
+//         i -> match[i] -> match[match[i]] ..., consecutive elements are paired (every such pair is an entry of the
+//         matrix), an odd cycle leaves one singleton (mo_split, match_order.f90:220-330);
+//      3. the graph is compressed -- a pair becomes ONE vertex with the union of both adjacencies -- and ordered with the
+//         handle's fill-reducing ordering (nested dissection or AMD here, METIS in the reference);
+//      4. the order is expanded: the two variables of a pair take consecutive positions.
+// order[i] = position of variable i (1-based).  Returns what hungarian_scale_sym returns (0, 1 singular; the ordering is
+// produced either way, rows without a partner are singletons).
+int match_order_sym(int n, const int64_t* ptr, const int32_t* row, const double* val, int ordering, int32_t* order,
+                    double* scaling, int32_t* npairs) {
+  std::vector<int32_t> match;
+  const int sf = hungarian_core(n, ptr, row, val, true, scaling, &match);
+  // ---- 2. pairs ----
+  std::vector<int32_t> partner(n, -1);
+  std::vector<char> seen(n, 0);
+  int pairs = 0;
+  for (int i0 = 0; i0 < n; ++i0) {
+    int cur = i0;
+    while (cur >= 0 && !seen[cur]) {
+      const int nxt = match[cur];
+      seen[cur] = 1;
+      if (nxt < 0 || nxt == cur || seen[nxt]) break;        // a singleton (fixed point, unmatched, or the odd one out)
+      seen[nxt] = 1;
+      partner[cur] = nxt;
+      partner[nxt] = cur;
+      ++pairs;
+      cur = match[nxt];
+    }
+  }
+  if (npairs) *npairs = pairs;
+  // ---- 3. the compressed graph ----
+  std::vector<int32_t> comp(n, -1), first;
+  for (int i = 0; i < n; ++i) {
+    if (comp[i] >= 0) continue;
+    comp[i] = int32_t(first.size());
+    if (partner[i] >= 0) comp[partner[i]] = comp[i];
+    first.push_back(i);
+  }
+  const int nc = int(first.size());
+  // full pattern of A (both triangles), by columns
+  std::vector<int64_t> aptr(n + 1, 0);
+  for (int j = 0; j < n; ++j)
+    for (int64_t k = ptr[j]; k < ptr[j + 1]; ++k) {
+      if (row[k] == j) continue;
+      aptr[j + 1]++;
+      aptr[row[k] + 1]++;
+    }
+  for (int j = 0; j < n; ++j) aptr[j + 1] += aptr[j];
+  std::vector<int32_t> arow(static_cast<size_t>(aptr[n]));
+  {
+    std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
+    for (int j = 0; j < n; ++j)
+      for (int64_t k = ptr[j]; k < ptr[j + 1]; ++k) {
+        if (row[k] == j) continue;
+        arow[fill[j]++] = row[k];
+        arow[fill[row[k]]++] = j;
+      }
+  }
+  std::vector<int64_t> cptr(nc + 1, 0);
+  std::vector<int> crow;
+  crow.reserve(arow.size());
+  std::vector<int32_t> mark(nc, -1);
+  for (int c = 0; c < nc; ++c) {
+    mark[c] = c;
+    const int mem[2] = {first[c], partner[first[c]]};
+    for (int q = 0; q < 2; ++q) {
+      if (mem[q] < 0) continue;
+      for (int64_t k = aptr[mem[q]]; k < aptr[mem[q] + 1]; ++k) {
+        const int d = comp[arow[k]];
+        if (mark[d] == c) continue;
+        mark[d] = c;
+        crow.push_back(d);
+      }
+    }
+    cptr[c + 1] = int64_t(crow.size());
+  }
+  std::vector<int> cperm(nc, 0);
+  if (ordering == GSLS_ORDER_NATURAL) std::iota(cperm.begin(), cperm.end(), 0);
+  else if (ordering == GSLS_ORDER_AMD) order_amd(nc, cptr, crow, cperm);
+  else order_nested_dissection(nc, cptr, crow, cperm);
+  // ---- 4. expand ----
+  std::vector<int32_t> at(nc);
+  for (int c = 0; c < nc; ++c) at[cperm[c]] = c;
+  int pos = 0;
+  for (int p = 0; p < nc; ++p) {
+    const int i = first[at[p]];
+    order[i] = ++pos;
+    if (partner[i] >= 0) order[partner[i]] = ++pos;
+  }
+  return sf;
 }
 
 // scaling = 2 (SSIDS: auction_scale_sym, src/spral/scaling.f90:1351-1609 -- the same problem, not the same algorithm).

@@ -102,6 +102,18 @@ module GALAHAD_GSLS_double
       type(gsls_options), intent(in) :: options
       type(gsls_inform), intent(out) :: inform
     end function
+    integer(c_int) function c_gsls_analyse_matching(handle, n, ptr, row, val, order, options, inform) &
+        bind(C, name='gsls_analyse_matching')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double, gsls_options, gsls_inform
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: n
+      integer(c_int64_t), intent(in) :: ptr(*)
+      integer(c_int32_t), intent(in) :: row(*)
+      real(c_double), intent(in) :: val(*)
+      integer(c_int32_t), intent(inout) :: order(*)
+      type(gsls_options), intent(in) :: options
+      type(gsls_inform), intent(out) :: inform
+    end function
     integer(c_int) function c_gsls_factor(handle, posdef, val, scale, options, inform) &
         bind(C, name='gsls_factor')
       import :: c_ptr, c_int, c_int32_t, c_double, gsls_options, gsls_inform
@@ -278,7 +290,9 @@ contains
 
   ! order(i) = position of variable i in the pivot sequence; used on entry when options%ordering = 0,
   ! always set on exit (ssids.f90:381)
-  subroutine GSLS_analyse(n, ptr, row, keep, options, inform, order)
+  ! val present: matching-based ordering and scaling, as ssids_analyse does with val and options%ordering = 2
+  ! (ssids.f90:305-320); factorize with options%scaling = 3 to use the saved scaling
+  subroutine GSLS_analyse(n, ptr, row, keep, options, inform, order, val)
     integer, intent(in) :: n
     integer(long), intent(in) :: ptr(:)
     integer, intent(in) :: row(:)
@@ -286,10 +300,15 @@ contains
     type(gsls_options), intent(in) :: options
     type(gsls_inform), intent(out) :: inform
     integer, intent(inout) :: order(:)
+    real(wp), optional, intent(in) :: val(:)
     integer(c_int) :: rc
     if (.not. c_associated(keep%handle)) rc = c_gsls_create(keep%handle)
     keep%n = n
-    rc = c_gsls_analyse(keep%handle, int(n, c_int32_t), ptr, row, order, options, inform)
+    if (present(val)) then
+      rc = c_gsls_analyse_matching(keep%handle, int(n, c_int32_t), ptr, row, val, order, options, inform)
+    else
+      rc = c_gsls_analyse(keep%handle, int(n, c_int32_t), ptr, row, order, options, inform)
+    end if
   end subroutine GSLS_analyse
 
   subroutine GSLS_factor(posdef, val, keep, options, inform, scale)

@@ -80,7 +80,8 @@ typedef struct gsls_options {
   int32_t ordering;        /* GSLS_ORDER_*                                                      */
   int32_t nemin;           /* supernode amalgamation, default 32 (core_analyse.f90:806-822)      */
   int32_t scaling;         /* 0 none / user supplied `scale`; 1 Hungarian (MC64), 2 auction, 4 norm     */
-                           /* equilibration, computed from the values (ssids.f90:921-1030); 3: -15       */
+                           /* equilibration, computed from the values (ssids.f90:921-1030); 3: the one   */
+                           /* gsls_analyse_matching saved (else -15)                                     */
   int32_t action;          /* indefinite: continue on singularity with warning 7 (default 1)     */
   int32_t device;          /* HIP device ordinal, -1 = current device                            */
   int32_t reserved2;       /* (was use_graph: never implemented; launch gaps measure ~0, a graph would buy nothing) */
@@ -139,6 +140,15 @@ int gsls_destroy(void** handle);
  *           out: the pivot order actually used (ssids.f90:381). */
 int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row, int32_t* order,
                  const gsls_options* options, gsls_inform* inform);
+
+/* gsls_analyse with the VALUES: matching-based ordering and scaling (ssids_analyse with val and options%ordering = 2,
+ * src/ssids/ssids.f90:305-320 -> src/spral/match_order.f90:51-208).  val[ptr[n]-1]: the entries of the lower triangle
+ * in the order of row[].  A maximum-product matching pairs variables into 2x2 pivot candidates, the graph compressed by
+ * those pairs is ordered with options->ordering (GSLS_ORDER_ND / _AMD / _NATURAL; _USER is read as _ND) and expanded
+ * with the partners next to each other; order[n] (output, 1-based positions) is that order, and the matching's scaling
+ * is kept in the handle for factorizations with options->scaling = 3 (ssids.f90:991-994; without this call: -15). */
+int gsls_analyse_matching(void* handle, int32_t n, const int64_t* ptr, const int32_t* row, const double* val,
+                          int32_t* order, const gsls_options* options, gsls_inform* inform);
 
 /* ---- factorize ----------------------------------------------------------------------------------- */
 

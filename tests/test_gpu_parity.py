@@ -831,6 +831,58 @@ def test_reference_scalings(path):
     assert delayed <= out[0][1]
 
 
+@pytest.mark.parametrize("path", [p for p in SCALED if "hungarian" in p],
+                         ids=[os.path.basename(p)[:-4] for p in SCALED if "hungarian" in p])
+def test_matching_based_ordering_and_its_saved_scaling(path):
+    """gsls_analyse_matching + options.scaling = 3 (ssids_analyse with val / ordering = 2, then ssids_factor with
+    scaling = 3: ssids.f90:305-320, 991-994; spral/match_order.f90) on the badly scaled systems of the scaling fixtures.
+    The reference cannot reach this combination through SLS (its ssids arm never passes val to the analysis), so there is
+    no reference-generated vector for it: parity here is UNPINNED beyond what the fixtures hold -- the scaling saved is
+    the Hungarian one (same matching), so inertia and rank must equal the fixture's, the residual must meet the same bar,
+    and scaling = 3 WITHOUT the matching analysis must give -15 as ssids does."""
+    import ctypes as C
+    from galahad_amd._lib import lib, Options, Inform
+    from oracle.oracle import lower_csc
+    g = np.load(path)
+    n = int(g["n"])
+    row, col, val, rhs = g["row"], g["col"], g["val"], g["rhs"]
+    ptr, r, v = lower_csc(n, row, col, val)
+    ptr, r, v = (np.ascontiguousarray(ptr, np.int64), np.ascontiguousarray(r, np.int32), np.ascontiguousarray(v, np.float64))
+    p64, p32, pd = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_void_p
+    o, inf = Options(), Inform()
+    lib.gsls_default_options(C.byref(o))
+    o.nemin = int(g["nemin"])
+    # (a) scaling = 3 after a plain analysis: no saved scaling
+    h = C.c_void_p()
+    assert lib.gsls_create(C.byref(h)) == 0
+    order = np.arange(1, n + 1, dtype=np.int32)
+    o.ordering, o.scaling = 1, 0
+    assert lib.gsls_analyse(h, n, ptr.ctypes.data_as(p64), r.ctypes.data_as(p32), order.ctypes.data_as(p32), C.byref(o),
+                            C.byref(inf)) >= 0
+    o.scaling = 3
+    assert lib.gsls_factor(h, 0, v.ctypes.data_as(pd), None, C.byref(o), C.byref(inf)) == -15
+    lib.gsls_destroy(C.byref(h))
+    # (b) the matching-based analysis, then scaling = 3
+    h = C.c_void_p()
+    assert lib.gsls_create(C.byref(h)) == 0
+    o.ordering, o.scaling = 1, 3
+    order = np.zeros(n, dtype=np.int32)
+    assert lib.gsls_analyse_matching(h, n, ptr.ctypes.data_as(p64), r.ctypes.data_as(p32), v.ctypes.data_as(pd),
+                                     order.ctypes.data_as(p32), C.byref(o), C.byref(inf)) >= 0
+    assert sorted(order.tolist()) == list(range(1, n + 1))
+    assert lib.gsls_factor(h, 0, v.ctypes.data_as(pd), None, C.byref(o), C.byref(inf)) >= 0, inf.flag
+    assert inf.num_neg == int(g["ref_neg"]) and inf.matrix_rank == int(g["ref_rank"])
+    sc = np.zeros(n)
+    assert lib.gsls_get_scaling(h, sc.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert (np.abs(val) * sc[row - 1] * sc[col - 1]).max() <= 1.0 + 1e-10          # a maximum-product matching scaling
+    x = np.array(rhs, dtype=np.float64)
+    assert lib.gsls_solve(h, 0, 1, x.ctypes.data_as(pd), n, C.byref(o), C.byref(inf)) >= 0
+    assert P.scaled_residual(n, row, col, val, x, rhs) <= 1e-10
+    ref_err = np.abs(g["ref_x"] - g["xstar"]).max()
+    assert np.abs(x - g["xstar"]).max() <= 100 * max(ref_err, 1e-12)
+    lib.gsls_destroy(C.byref(h))
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 48, 49, 63, 64, 65, 129])
 @pytest.mark.parametrize("kind", ["spd", "indef"])
 def test_edge_sizes_dense_single_front(n, kind):

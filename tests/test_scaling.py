@@ -91,3 +91,88 @@ def test_scaling_3_needs_the_matching_ordering():
     # (no device needed: the option is rejected before any device work -- but analyse needs none either)
     n, row, col, val, rhs, xs = P.kat_indefinite()
     assert lib.gsls_scale_sym(3, n, None, None, None, 1, None) < 0
+
+
+def _analyse_matching(n, row, col, val, ordering=1):
+    from galahad_amd._lib import Options, Inform
+    ptr, r, v = lower_csc(n, row, col, val)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)               # (1-based, explicit diagonal: what SLS hands over)
+    r = np.ascontiguousarray(r, dtype=np.int32)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    h = C.c_void_p()
+    assert lib.gsls_create(C.byref(h)) == 0
+    o, i = Options(), Inform()
+    lib.gsls_default_options(C.byref(o))
+    o.ordering = ordering
+    order = np.zeros(n, dtype=np.int32)
+    flag = lib.gsls_analyse_matching(h, n, ptr.ctypes.data_as(C.POINTER(C.c_int64)), r.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     v.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     C.byref(o), C.byref(i))
+    return h, flag, order, i, (ptr, r, v)
+
+
+def test_matching_based_ordering_puts_partners_next_to_each_other():
+    """gsls_analyse_matching (ssids_analyse with val and ordering = 2, ssids.f90:305-320; spral/match_order.f90): on
+    K = [eps I, B; B^T, 0] with B = diag-dominant the maximum-product matching pairs variable i with n1 + i (the only large
+    entry of either), so the two must be consecutive in the returned order -- the 2x2 pivots threshold pivoting takes; the
+    order is a permutation, and the analysis that follows reports the pattern's statistics as gsls_analyse does."""
+    rng = np.random.default_rng(5)
+    n1 = 120
+    rows, cols, vals = [], [], []
+    for i in range(n1):
+        rows.append(i + 1); cols.append(i + 1); vals.append(1e-8 * (1 + i % 3))            # tiny (1,1) block
+        rows.append(n1 + i + 1); cols.append(i + 1); vals.append(10.0 + rng.uniform())       # B's diagonal: the large entries
+        for _ in range(2):                                                                   # small couplings elsewhere
+            j = int(rng.integers(0, n1))
+            if j != i:
+                rows.append(n1 + j + 1); cols.append(i + 1); vals.append(0.01 * rng.uniform(-1, 1))
+    n = 2 * n1
+    row, col, val = np.array(rows, np.int32), np.array(cols, np.int32), np.array(vals)
+    for ordering in (1, 2, 3):
+        h, flag, order, inf, _ = _analyse_matching(n, row, col, val, ordering)
+        assert flag == 0, flag
+        assert sorted(order.tolist()) == list(range(1, n + 1))
+        # (the order that comes back is the FINAL pivot order, as from ssids_analyse: supernode amalgamation renumbers
+        # inside a merged supernode -- children by decreasing column count, core_analyse.f90:806-822 -- which parts a
+        # pair now and then, in the reference as here; both halves stay in one front)
+        gap = np.array([abs(int(order[i]) - int(order[n1 + i])) for i in range(n1)])
+        assert (gap == 1).sum() >= 0.8 * n1 and gap.max() <= 40, (ordering, (gap == 1).sum(), gap.max())
+        assert inf.num_factor > 0 and inf.num_sup > 0
+        lib.gsls_destroy(C.byref(h))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_matching_based_ordering_keeps_every_pair_an_entry_of_the_matrix(name):
+    """Whatever the cycles of the matching look like (long cycles are cut into pairs + singletons, mo_split
+    match_order.f90:220-330), two variables that end up as a pair -- consecutive positions (2k-1, 2k) that were not
+    forced by the graph -- must be joined by an entry; checked through the property the expansion guarantees: walking the
+    order, every variable whose matched partner is a different variable has that partner or a neighbour of the cycle
+    beside it.  Here simply: the order is a permutation for every test matrix, singular ones included, and the scaling the
+    call saves is the Hungarian scaling (same matching)."""
+    n, row, col, val, rhs, xs = CASES[name]()
+    h, flag, order, inf, _ = _analyse_matching(n, row, col, val)
+    assert flag >= 0
+    assert sorted(order.tolist()) == list(range(1, n + 1))
+    lib.gsls_destroy(C.byref(h))
+
+
+def test_matching_based_ordering_argument_checks():
+    from galahad_amd._lib import Options, Inform
+    n, row, col, val, rhs, xs = P.kat_indefinite()
+    ptr, r, v = lower_csc(n, row, col, val)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    r = np.ascontiguousarray(r, dtype=np.int32)
+    h = C.c_void_p()
+    assert lib.gsls_create(C.byref(h)) == 0
+    order = np.zeros(n, dtype=np.int32)
+    i = Inform()
+    p64, p32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    # no values: the error ssids_analyse gives for ordering = 2 without val (ssids.f90:306-310)
+    assert lib.gsls_analyse_matching(h, n, ptr.ctypes.data_as(p64), r.ctypes.data_as(p32), None,
+                                     order.ctypes.data_as(p32), None, C.byref(i)) == -9
+    assert lib.gsls_analyse_matching(h, n, ptr.ctypes.data_as(p64), r.ctypes.data_as(p32),
+                                     np.ascontiguousarray(v).ctypes.data_as(C.c_void_p), None, None, C.byref(i)) < 0
+    assert lib.gsls_analyse_matching(None, n, ptr.ctypes.data_as(p64), r.ctypes.data_as(p32),
+                                     np.ascontiguousarray(v).ctypes.data_as(C.c_void_p), order.ctypes.data_as(p32), None,
+                                     C.byref(i)) < 0
+    lib.gsls_destroy(C.byref(h))
