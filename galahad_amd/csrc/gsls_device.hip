@@ -3136,6 +3136,65 @@ __device__ __forceinline__ void wave_fwd_compute(const WTask& t, int lane, const
   }
 }
 
+// wave_fwd_compute for CG columns at once (narrow launches: no pulls): the same operations per column in the same
+// order -- every column's result carries the bits of a single-column solve -- with the CG recurrences interleaved, so that
+// one column's v_readlane -> FMA dependency is covered by the others' (these launches run at two or three waves per SIMD:
+// CG sets of LDS accumulators per wave).  Column c works in acc + c * ACCW, xp + c * sx, slotv + c * sxs, cvec + c * scv.
+template <int NN, bool APPLY_D, int AS, int CG>
+__device__ __forceinline__ void wave_fwd_compute_cg(const WTask& t, int lane, const WFwdPre<NN>& p, const double (&rhs)[CG],
+                                                    double* __restrict__ acc, int accw, double* __restrict__ xp, int64_t sx,
+                                                    double* __restrict__ slotv, int64_t sxs, double* __restrict__ cvec,
+                                                    int64_t scv) {
+  const int m = t.m, n = t.n;
+  const int spare = accw - 64;          // the row for the masked lanes sits behind the launch's deepest slot
+  double x[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    double csum = 0.0;
+    if (t.flags & WT_INT) {
+      double* mine = acc + c * accw + t.myslot * AS;
+      if (AS == 64 || lane < AS) {
+        csum += mine[lane];
+        mine[lane] = 0.0;
+      }
+    }
+    x[c] = __shfl(rhs[c] + csum, p.pslot);
+  }
+#pragma unroll
+  for (int k4 = 0; k4 < NN; k4 += 4) {
+    if (k4 < 16 || k4 < n) {
+#pragma unroll
+      for (int k = k4; k < k4 + 4; ++k) {
+        const double l = (k & 1) ? p.lp[k >> 1].y : p.lp[k >> 1].x;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+          const double yk = readlane_f64(x[c], k);
+          x[c] = fma(-l, yk, x[c]);
+        }
+      }
+    }
+  }
+  const bool crow = (lane >= n) & (lane < m);
+  const bool push = (t.flags & WT_PUSH) != 0;
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    double* a = acc + c * accw + ((crow & push) ? t.pslot * AS + p.prow : spare + lane);
+    *a += (crow & push) ? x[c] : 0.0;
+    if (!push && crow) cvec[c * scv + t.moff + lane - n] = x[c];
+    double y = x[c];
+    if (APPLY_D) {
+      const double yp = __shfl_up(y, 1), yn = __shfl_down(y, 1);
+      if (isinf(p.d0)) y = fma(p.dp, yp, p.d1 * y);
+      else if (isinf(p.dn)) y = fma(p.d0, y, p.d1 * yn);
+      else y = y * p.d0;
+    }
+    if (lane < n) {
+      if (slotv) slotv[c * sxs + t.sptr + lane] = y;
+      else xp[c * sx + t.sptr + p.pslot] = y;
+    }
+  }
+}
+
 template <int MM>
 struct WBwdPre {
   double2_t up[MM / 2];
@@ -3326,6 +3385,45 @@ __device__ __forceinline__ void wave_bwd_compute(const WTask& t, int lane, const
   }
 }
 
+// wave_bwd_compute for CG columns at once (narrow launches: no pulls), as wave_fwd_compute_cg
+template <int MM, int AS, int CG>
+__device__ __forceinline__ void wave_bwd_compute_cg(const WTask& t, int lane, const WBwdPre<MM>& p, const double (&xin)[CG],
+                                                    double* __restrict__ xfull, int accw, double* __restrict__ xp, int64_t sx,
+                                                    double* __restrict__ xout, int64_t sio) {
+  const int m = t.m, n = t.n;
+  double x[CG];
+  const bool prow = ((t.flags & WT_PUSH) != 0) & (lane >= n) & (lane < m);
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    const double xv = xfull[c * accw + (prow ? t.pslot * AS + p.prow : accw - 64 + lane)];
+    x[c] = prow ? xv : xin[c];
+  }
+#pragma unroll
+  for (int j4 = MM - 4; j4 >= 0; j4 -= 4) {
+    if (j4 < 24 || j4 < m) {
+#pragma unroll
+      for (int j = j4 + 3; j >= j4; --j) {
+        if (j == 0) continue;
+        const double u = (j & 1) ? p.up[j >> 1].y : p.up[j >> 1].x;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+          const double xj = readlane_f64(x[c], j);
+          x[c] = fma(-u, xj, x[c]);
+        }
+      }
+    }
+  }
+  const int arow = (lane < n) ? p.pos - t.sptr : lane;
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    if ((t.flags & WT_INT) && (AS == 64 || lane < m)) xfull[c * accw + t.myslot * AS + arow] = x[c];
+    if (lane < n) {
+      xp[c * sx + p.pos] = x[c];
+      if (xout) xout[c * sio + p.var] = x[c];
+    }
+  }
+}
+
 __device__ __forceinline__ WTask wave_task(const WTask* __restrict__ tasks, int idx) {
   return tasks[__builtin_amdgcn_readfirstlane(idx)];
 }
@@ -3333,26 +3431,37 @@ __device__ __forceinline__ WTask wave_task(const WTask* __restrict__ tasks, int 
 // NARROW: every front of the launch has at most 32 pivot columns: the loads of the group's next front are in flight
 // while the wave works on the current one (two register sets, A and B).  Otherwise fronts of 33..64 columns are
 // among them: one at a time (two 64-column register sets do not fit).
-template <bool APPLY_D, bool NARROW, bool FLAT = false>
+// CG (narrow flat launches, several right-hand sides): ONE wave takes a front for CG columns -- the image, D and the maps
+// are loaded once and the recurrence runs CG times on them, each column with its own right-hand side, LDS accumulators
+// and vectors (cs.R counts column GROUPS then).  The bottom stage of a KKT tree is bound by the memory system, not by
+// the arithmetic: with a launch per column (CG = 1, grid x R) eight columns read the 170 MB image eight times.
+// (Tried on top and dropped: the next front's loads in flight during this front's CG recurrences -- 0.60 -> 0.62 ms
+// for eight columns.)
+template <bool APPLY_D, bool NARROW, bool FLAT = false, int CG = 1>
 __global__ void __launch_bounds__(256)
 k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restrict__ tasks,
              const double* __restrict__ Lf, const double* __restrict__ D, const int32_t* __restrict__ gperm,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, double* __restrict__ slotv,
              double* __restrict__ cvec, Cols cs, const int32_t* __restrict__ pull2, int unit_tbeg, int wimg_units) {
+  static_assert(CG == 1 || (NARROW && FLAT), "column groups: narrow flat launches only");
   constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
-  __shared__ double accs[4][WSLOT * AS + 64];     // + a spare row (64 wide) for the masked lanes
+  // accumulators: a row per LDS slot + a spare row (64 wide) for the masked lanes.  CG = 1: WSLOT rows, static; column
+  // groups: the launch's deepest slot (wimg_units carries it), CG sets per wave in dynamic LDS -- what decides how many
+  // waves share a CU there
+  const int depth = (CG > 1) ? wimg_units : WSLOT;
+  const int ACCW = depth * AS + 64;
+  __shared__ double accs[CG > 1 ? 1 : 4][CG > 1 ? 1 : WSLOT * AS + 64];
   extern __shared__ __attribute__((aligned(16))) double2_t wdyn[];    // wide launches: wimg_units 16-byte units per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GSLS_COLS;
-  xp += col_ * cs.sx;
-  cvec += col_ * cs.scv;
-  if (slotv) slotv += col_ * cs.sxs;
+  xp += col_ * CG * cs.sx;
+  cvec += col_ * CG * cs.scv;
+  if (slotv) slotv += col_ * CG * cs.sxs;
   const int gi = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
   if (gi >= ngroup) return;
-  double* acc = accs[wave];
-#pragma unroll
-  for (int i = 0; i < WSLOT * AS + 64; i += 64) acc[i + lane] = 0.0;
+  double* acc = (CG > 1) ? reinterpret_cast<double*>(wdyn) + wave * CG * ACCW : accs[wave];
+  for (int i = 0; i < CG * ACCW; i += 64) acc[i + lane] = 0.0;
   // unit_tbeg >= 0: every run of this launch is ONE front, run gi = task unit_tbeg + gi -- no group record to fetch
   // (a stage of the upper tree is a chain of dependent round trips: this is one of them)
   const WGroup g = (unit_tbeg >= 0) ? WGroup{unit_tbeg + gi, 1} : groups[gi];
@@ -3376,10 +3485,13 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
     while (true) {
       const WTask tb = wave_task(tasks, min(ti + 1, te - 1));
       WFwdPre<32> A;
+      double rhsx[CG];                    // the other columns' right-hand sides (rhsx[0] unused)
       if constexpr (FLAT) {
         __shared__ __attribute__((aligned(16))) double2_t wimg[4][WIMG_BYTES / 16];
         WFwdFlat<APPLY_D> Q;
         wave_fwd_issue<APPLY_D>(ta, lane, Q, Lf, D, gperm, cmap, xp);
+#pragma unroll
+        for (int c = 1; c < CG; ++c) rhsx[c] = wave_ld_f64(wave_rsrc(xp + c * cs.sx + ta.sptr, ta.n * 8), lane * 8);
         wave_fwd_arrive<APPLY_D>(ta, lane, Q, A, wimg[wave]);
       } else {
         wave_fwd_load<32, APPLY_D>(ta, lane, A, Lf, D, gperm, cmap, xp);
@@ -3389,7 +3501,12 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
       WPH(ph0);                           // image, right-hand side, D, maps: issue -> arrival
       ++nfr;
 #endif
-      wave_fwd_compute<32, APPLY_D, false, AS>(ta, lane, A, acc, gth_ptr, gth_src, xp, slotv, cvec);
+      if constexpr (CG > 1) {
+        rhsx[0] = A.rhs;
+        wave_fwd_compute_cg<32, APPLY_D, AS, CG>(ta, lane, A, rhsx, acc, ACCW, xp, cs.sx, slotv, cs.sxs, cvec, cs.scv);
+      } else {
+        wave_fwd_compute<32, APPLY_D, false, AS>(ta, lane, A, acc, gth_ptr, gth_src, xp, slotv, cvec);
+      }
 #ifdef GSLS_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       WPH(ph1);                           // recurrence, LDS hand-off, stores issued (and the next task record arrived)
@@ -3424,7 +3541,7 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
 }
 
 // NARROW: every front of the launch has at most 40 rows (two register sets, as in the forward kernel)
-template <bool NARROW, bool FLAT = false>
+template <bool NARROW, bool FLAT = false, int CG = 1>
 __global__ void __launch_bounds__(256)
 k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restrict__ tasks,
              const double* __restrict__ Lb, const int32_t* __restrict__ gperm, const int32_t* __restrict__ gvar,
@@ -3432,18 +3549,21 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, const double* __restrict__ slotv,
              double* __restrict__ xout, const double* __restrict__ scale, double* __restrict__ cvec, Cols cs,
              const int32_t* __restrict__ pull2, int unit_tbeg, int wimg_units) {
+  static_assert(CG == 1 || (NARROW && FLAT), "column groups: narrow flat launches only");
   constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
-  __shared__ double xfs[4][WSLOT * AS + 64];
+  const int depth = (CG > 1) ? wimg_units : WSLOT;     // (as in the forward kernel)
+  const int ACCW = depth * AS + 64;
+  __shared__ double xfs[CG > 1 ? 1 : 4][CG > 1 ? 1 : WSLOT * AS + 64];
   extern __shared__ __attribute__((aligned(16))) double2_t wdyn[];    // wide launches: wimg_units 16-byte units per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GSLS_COLS;
-  xp += col_ * cs.sx;
-  cvec += col_ * cs.scv;
-  if (slotv) slotv += col_ * cs.sxs;
-  if (xout) xout += col_ * cs.sio;
+  xp += col_ * CG * cs.sx;
+  cvec += col_ * CG * cs.scv;
+  if (slotv) slotv += col_ * CG * cs.sxs;
+  if (xout) xout += col_ * CG * cs.sio;
   const int gi = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
   if (gi >= ngroup) return;
-  double* xfull = xfs[wave];
+  double* xfull = (CG > 1) ? reinterpret_cast<double*>(wdyn) + wave * CG * ACCW : xfs[wave];
   const WGroup g = (unit_tbeg >= 0) ? WGroup{unit_tbeg + gi, 1} : groups[gi];
   const bool wv = xout != nullptr;
   if constexpr (NARROW) {
@@ -3452,15 +3572,28 @@ k_wsolve_bwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
     while (true) {
       const WTask tb = wave_task(tasks, max(ti - 1, g.tbeg));
       WBwdPre<40> A;
+      double xcol[CG];                    // (xcol[0] unused)
       if constexpr (FLAT) {
         __shared__ __attribute__((aligned(16))) double2_t wimg[4][WIMG_BYTES / 16];
         WBwdFlat Q;
         wave_bwd_issue(ta, lane, Q, Lb, gperm, gvar, cmap, slotv, cvec);
+#pragma unroll
+        for (int c = 1; c < CG; ++c) {      // the other columns' forward results and ancestors' values (as Q.xs / Q.z)
+          const int co = lane >= ta.n ? (lane - ta.n) * 8 : int(0x80000000);
+          const double xs = wave_ld_f64(wave_rsrc(slotv + c * cs.sxs + ta.sptr, ta.n * 8), lane * 8);
+          const double z = wave_ld_f64(wave_rsrc(cvec + c * cs.scv + ta.moff, (ta.m - ta.n) * 8), co);
+          xcol[c] = (lane < ta.n) ? xs : z;
+        }
         wave_bwd_arrive(ta, lane, Q, A, wimg[wave]);
       } else {
         wave_bwd_load<40, true>(ta, lane, A, Lb, wdyn + wave * wimg_units, gperm, gvar, cmap, rlist, xp, slotv, cvec, wv);
       }
-      wave_bwd_compute<40, false, AS>(ta, lane, A, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+      if constexpr (CG > 1) {
+        xcol[0] = A.x;
+        wave_bwd_compute_cg<40, AS, CG>(ta, lane, A, xcol, xfull, ACCW, xp, cs.sx, xout, cs.sio);
+      } else {
+        wave_bwd_compute<40, false, AS>(ta, lane, A, xfull, gth_ptr, gth_src, xp, xout, scale, cvec);
+      }
       if (--ti < g.tbeg) break;
       ta = tb;
     }
@@ -4439,6 +4572,13 @@ static hipError_t allow_big_lds() {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front_discover), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * DISC_LD * 8));
+  // (column groups: CG sets of LDS accumulators per wave, dynamic, next to 24 KB of static image staging)
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<true, true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<true, true, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<false, true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_fwd<false, true, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_bwd<true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_bwd<true, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve_tail<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   return hipSuccess;
@@ -4842,6 +4982,12 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
           wp[ti] = WPack{S.loff[s], s, 0};
         }
       }
+      // deepest LDS slot the narrow runs of each stage use (the column-group launches size their accumulators by it)
+      F.wstage_ndepth.assign(nstage, 1);
+      for (int k = 0; k < nstage; ++k)
+        for (int r = F.wstage_begin[k]; r < F.wstage_begin[k] + F.wstage_narrow[k]; ++r)
+          for (int64_t ti = wg[r].tbeg; ti < int64_t(wg[r].tbeg) + wg[r].tcnt; ++ti)
+            F.wstage_ndepth[k] = std::max(F.wstage_ndepth[k], std::max(wt[ti].myslot, wt[ti].pslot) + 1);
       // images and gather lists in launch order (run by run; laying the images out in the order the waves of a launch
       // reach them -- the k-th fronts of all runs next to each other -- was measured: no difference)
       int64_t of = 0, ob = 0;
@@ -5754,19 +5900,47 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   // (experiment knob: unused dynamic LDS per workgroup of the narrow wave kernels = fewer waves per CU)
   static const size_t ws_pad = getenv("GSLS_WS_LDSPAD") ? size_t(atoi(getenv("GSLS_WS_LDSPAD"))) : 0;
   static const bool ws_flat = !(getenv("GSLS_WS_FLAT") && atoi(getenv("GSLS_WS_FLAT")) == 0);   // (A/B knob)
-  auto wave_fwd = [&](int g0, int cnt, bool narrow, int unit = -1) {
+  // columns per wave in the narrow flat launches (several right-hand sides): 4, 2 or 1, whatever divides R
+  static const int colgrp_max = getenv("GSLS_WS_COLGRP") ? atoi(getenv("GSLS_WS_COLGRP")) : 4;
+  const int colgrp = (R > 1 && colgrp_max >= 4 && R % 4 == 0) ? 4 : (R > 1 && colgrp_max >= 2 && R % 2 == 0) ? 2 : 1;
+  auto wave_fwd = [&](int g0, int cnt, bool narrow, int unit = -1, int depth = WSLOT) {
     if (cnt <= 0) return;
 #define GSLS_WFWD(D_, N_, F_)                                                                                      \
   hipLaunchKernelGGL((k_wsolve_fwd<D_, N_, F_>), dim3(((cnt + 3) / 4) * R), dim3(256),                                        \
                      (N_) ? ws_pad : 0, st, wgr + g0, cnt, wtk, F.Lf, F.D, \
                      F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cs, F.wpull2, unit, F.wimg_units)
+    if (narrow && ws_flat && colgrp > 1) {
+      // several columns per wave (template parameter CG): cs.R counts the column groups in these launches
+      Cols cg = cs;
+      cg.R = R / colgrp;
+#define GSLS_WFWDG(D_, G_)                                                                                                    \
+  hipLaunchKernelGGL((k_wsolve_fwd<D_, true, true, G_>), dim3(((cnt + 3) / 4) * cg.R), dim3(256),                                 \
+                     size_t(4) * G_ * (depth * WACC_NARROW + 64) * 8, st, wgr + g0, cnt, wtk,                                     \
+                     F.Lf, F.D, F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv, w_cvec, cg, F.wpull2, unit, depth)
+      if (colgrp == 4) { if (fuse_d) GSLS_WFWDG(true, 4); else GSLS_WFWDG(false, 4); }
+      else { if (fuse_d) GSLS_WFWDG(true, 2); else GSLS_WFWDG(false, 2); }
+#undef GSLS_WFWDG
+      return;
+    }
     if (fuse_d) { if (narrow) { if (ws_flat) GSLS_WFWD(true, true, true); else GSLS_WFWD(true, true, false); } else GSLS_WFWD(true, false, false); }
     else { if (narrow) { if (ws_flat) GSLS_WFWD(false, true, true); else GSLS_WFWD(false, true, false); } else GSLS_WFWD(false, false, false); }
 #undef GSLS_WFWD
   };
-  auto wave_bwd = [&](int g0, int cnt, bool narrow, int unit = -1) {
+  auto wave_bwd = [&](int g0, int cnt, bool narrow, int unit = -1, int depth = WSLOT) {
     if (cnt <= 0) return;
     const int wu = F.wimg_units;      // LDS staging area per wave of the wide launches (16-byte units)
+    if (narrow && ws_flat && colgrp > 1) {
+      Cols cg = cs;
+      cg.R = R / colgrp;
+      const size_t lds = size_t(4) * colgrp * (depth * WACC_NARROW + 64) * 8;
+      if (colgrp == 4)
+        hipLaunchKernelGGL((k_wsolve_bwd<true, true, 4>), dim3(((cnt + 3) / 4) * cg.R), dim3(256), lds, st, wgr + g0, cnt, wtk, F.Lf, F.gperm,
+                           F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cg, F.wpull2, unit, depth);
+      else
+        hipLaunchKernelGGL((k_wsolve_bwd<true, true, 2>), dim3(((cnt + 3) / 4) * cg.R), dim3(256), lds, st, wgr + g0, cnt, wtk, F.Lf, F.gperm,
+                           F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cg, F.wpull2, unit, depth);
+      return;
+    }
     if (narrow && ws_flat)
       hipLaunchKernelGGL((k_wsolve_bwd<true, true>), dim3(((cnt + 3) / 4) * R), dim3(256), ws_pad, st, wgr + g0, cnt, wtk, F.Lf, F.gperm,
                          F.gvar, F.cmap, F.rlist, F.wgth_ptr, F.wgth_src, xp, slotv, xout, scale, w_cvec, cs, F.wpull2, unit, wu);
@@ -5806,7 +5980,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   if (do_fwd && wave) {
     for (int k = 0; k < ktail; ++k) {                       // stages of small subtrees, bottom-up
       const int nar = ahead ? F.wstage_narrow[k] : 0;
-      wave_fwd(F.wstage_begin[k], nar, true);
+      wave_fwd(F.wstage_begin[k], nar, true, -1, k < int(F.wstage_ndepth.size()) ? F.wstage_ndepth[k] : WSLOT);
       wave_fwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false, nar == 0 ? F.wstage_unit[k] : -1);
     }
     if (ktail < nstage) wave_tail(1, tail_both ? 1 : 0);
@@ -5903,7 +6077,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
     for (int k = ktail - 1; k >= 0; --k) {
       const int nar = ahead ? F.wstage_narrow[k] : 0;
       wave_bwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false, nar == 0 ? F.wstage_unit[k] : -1);
-      wave_bwd(F.wstage_begin[k], nar, true);
+      wave_bwd(F.wstage_begin[k], nar, true, -1, k < int(F.wstage_ndepth.size()) ? F.wstage_ndepth[k] : WSLOT);
     }
   if (ev) HIPCHK(hipEventRecord(ev[3], st));
   return hipGetLastError();

@@ -704,7 +704,7 @@ def test_blocked_multi_rhs_equals_column_by_column(nrhs):
 
 
 @pytest.mark.parametrize("kind", ["kkt", "kkt_pivoting", "grid3d", "grid3d_chol", "scaled"])
-@pytest.mark.parametrize("nrhs", [2, 5, 9, 17])
+@pytest.mark.parametrize("nrhs", [2, 4, 5, 9, 16, 17])
 def test_multi_rhs_columns_in_one_launch_equal_column_by_column(kind, nrhs):
     """Several right-hand sides on the LDL^T path go through every launch of the single-column kernels together (up to
     eight columns: block b works on column b % R, struct Cols in gsls_device.hip; ssids_solve_mult, ssids.f90:1139-1249).
