@@ -4585,6 +4585,7 @@ static hipError_t allow_big_lds() {
 }
 
 hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st) {
+  F.pure_state = false;      // (gperm, D, gvar are rebuilt: dev_factor)
   const int me = F.myrank;
   dev_free(F);
   F.myrank = me;
@@ -5844,13 +5845,20 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
   // with the wave-per-front plan only the fronts of the workgroup kernels take their entries of A through the
   // rectangle in HBM (k_front_wave gathers its own); blacklisted fronts are workgroup fronts again: full scatter
   const bool part = use_tiny && F.bl_count == 0;
+  // pure: every front goes through the wave-per-front kernels (every front has its diagonal entry among A's, so no
+  // scatter entries for workgroup fronts = no workgroup fronts).  Those kernels eliminate in the given order: they never
+  // write gperm (it stays the identity), they write every pivot's two words of D and every front's image themselves.
+  // So on a handle whose last pass was pure as well, the identity in gperm, the zeroing of D, the pack kernel and
+  // gvar = invp o gperm are all in place already: four launches less per refactorization of the metric workload.
+  const bool pure = part && !posdef && F.nscatter_wg == 0 && F.wave;
+  const bool carry = pure && F.pure_state;
   F.cur_val = d_val;
   if (!part || F.nscatter_wg > 0)
     HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));
-  HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
+  if (!carry) HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4) * sizeof(double), st));
   static const std::vector<int32_t> init = [] { std::vector<int32_t> v(NSTAT, 0); v[0] = INT_MAX; return v; }();
   HIPCHK(hipMemcpyAsync(F.stat, init.data(), NSTAT * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_iota, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm);
+  if (!carry) hipLaunchKernelGGL(k_iota, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm);
   const int64_t nsc = part ? F.nscatter_wg : F.nscatter;
   if (nsc > 0) {
     const int blocks = int(std::min<int64_t>((nsc + 255) / 256, 256 * 8));
@@ -5863,11 +5871,12 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
   }
   hipError_t e = factor_levels<false>(S, F, use_tiny ? F.planT : F.plan, small, u, st);
   if (e != hipSuccess) return e;
-  if (F.wave && F.wtask_cnt > 0)   // packed images of the wave-tier fronts the workgroup kernels factorized
+  if (F.wave && F.wtask_cnt > 0 && !pure)   // packed images of the wave-tier fronts the workgroup kernels factorized
     hipLaunchKernelGGL(k_wpack, dim3((F.wtask_cnt + 3) / 4), dim3(256), 0, st, static_cast<const WTask*>(F.wtasks),
                        static_cast<const WPack*>(F.wpacks), F.wtask_cnt, use_tiny ? 1 : 0, F.tinyskip, F.L, F.Lf, F.Lb);
-  if (F.wave)
+  if (F.wave && !carry)
     hipLaunchKernelGGL(k_gvar, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.gperm, F.invp, F.gvar);
+  F.pure_state = pure;
   return hipGetLastError();
 }
 
@@ -6239,6 +6248,7 @@ hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool 
                             double* d_xchg, double small, double u, hipStream_t st, bool fast) {
   if (!F.sharded) return hipErrorInvalidValue;
   fast = fast && !posdef;
+  F.pure_state = false;
   F.cur_val = d_val;
   if (phase == 1) {
     HIPCHK(hipMemsetAsync(F.L, 0, std::max<int64_t>(F.L_elems, 1) * sizeof(double), st));

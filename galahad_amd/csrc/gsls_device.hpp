@@ -163,6 +163,7 @@ struct DeviceFactor {
   int64_t disc_pcap = 0;
   int wimg_units = 64;            // LDS staging area per wave of the wide backward launches (16-byte units)
   int32_t* wpull2 = nullptr;      // dense form of the gather lists for fronts with at most two sources per row
+  bool pure_state = false;        // the last factorization pass ran on the wave-per-front kernels only (dev_factor)
   std::vector<int> wstage_ndepth; // per stage: LDS slots its narrow runs use (1 + the deepest myslot / pslot)
   std::vector<int> wstage_unit;   // per stage: first task if every run is one front in task order, else -1
   int32_t* wgth_ptr = nullptr;    // gather lists of the covered fronts (rows -> children's contribution entries)
