@@ -73,6 +73,7 @@ struct Handle {
   int comm_ranks = 0, comm_rank = 0;
   double* cx_factor = nullptr;
   double* cx_solve = nullptr;
+  int32_t* stat_pin = nullptr;    // pinned landing place of the factorization counters (read_stat)
   double* cx_hostx = nullptr;     // gsls_comm_solve: the host caller's vector on the device
   int cx_hostx_cap = 0;
   int32_t* cx_fail = nullptr;     // nranks x (1 + GSLS_FAILCAP): every rank's failed pivots (all-gather)
@@ -305,6 +306,7 @@ int gsls_destroy(void** handle) {
     for (auto& ev : h->ev)
       if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stat_pin) (void)hipHostFree(h->stat_pin);
   }
   delete h;
   *handle = nullptr;
@@ -413,8 +415,14 @@ int gsls_analyse(void* handle, int32_t n, const int64_t* ptr, const int32_t* row
 // stat[] of the last factorization pass: copies the counters and folds the binned ones (device side: no
 // same-address atomics from tens of thousands of fronts) into st[2] (negative pivots) and st[6] (optimistic fronts)
 static hipError_t read_stat(Handle* h, int32_t (&st)[16]) {
-  int32_t all[NSTAT];
-  hipError_t e = hipMemcpyAsync(all, h->F.stat, sizeof(all), hipMemcpyDeviceToHost, h->stream);
+  // every factorization pass ends here, with the GPU idle until the host has seen the counters: a pinned destination
+  // (one DMA, no staging copy inside the runtime) keeps that round trip short
+  if (!h->stat_pin) {
+    hipError_t e0 = hipHostMalloc(reinterpret_cast<void**>(&h->stat_pin), NSTAT * sizeof(int32_t), hipHostMallocDefault);
+    if (e0 != hipSuccess) { h->stat_pin = nullptr; return e0; }
+  }
+  int32_t* all = h->stat_pin;
+  hipError_t e = hipMemcpyAsync(all, h->F.stat, NSTAT * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return e;

@@ -4,9 +4,14 @@ import os
 f=max(glob.glob(d+'/*/*_kernel_trace.csv'), key=os.path.getmtime)
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'k_iota' in r['Kernel_Name']]
-a=idx[-1]
-seg=rows[a-3:]
+# the last bench step = everything after the solve kernels of the step before it (a refactorization that runs on the
+# wave-per-front kernels only no longer launches k_iota, the old marker)
+names=[r['Kernel_Name'] for r in rows]
+def is_solve(n): return any(t in n for t in ('k_wsolve_','k_solve_','k_permute_out','k_big_','k_permute_in'))
+pin=max(i for i,n in enumerate(names) if 'k_permute_in' in n)
+a=pin-1
+while a>=0 and not is_solve(names[a]): a-=1
+seg=rows[a+1:]
 agg=collections.OrderedDict()
 for r in seg:
     k=r['Kernel_Name'][:34]

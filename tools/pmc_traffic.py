@@ -1,6 +1,6 @@
 """Sum the FETCH_SIZE / WRITE_SIZE counters (two rocprofv3 --pmc passes) over the kernels of the LAST
-bench step: the solve sweep (k_permute_in .. k_permute_out) and the factorization (k_iota .. before
-k_permute_in).  FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide coalesced reads at
+bench step: the solve sweep (k_permute_in .. k_permute_out) and the factorization (everything after the previous
+step's solve kernels .. before k_permute_in).  FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide coalesced reads at
 64 B, MI355X_MICROARCH.md); both counters are in KB."""
 import csv, glob, json, sys
 
@@ -19,8 +19,14 @@ def split(rows):
     names = [r['Kernel_Name'] for r in rows]
     pin = max(i for i, n in enumerate(names) if 'k_permute_in' in n)
     pout = max(i for i, n in enumerate(names) if i >= pin and ('k_permute_out' in n or 'k_wsolve_bwd' in n or 'k_solve_bwd' in n))
-    iota = max(i for i, n in enumerate(names) if 'k_iota' in n and i < pin)
-    return rows[iota:pin], rows[pin:pout + 1]
+    # the factorization starts right after the solve kernels of the step before (k_iota, the old marker, is not launched
+    # by a refactorization that runs on the wave-per-front kernels only)
+    def is_solve(n):
+        return any(t in n for t in ('k_wsolve_', 'k_solve_', 'k_permute_out', 'k_big_', 'k_permute_in'))
+    a = pin - 1
+    while a >= 0 and not is_solve(names[a]):
+        a -= 1
+    return rows[a + 1:pin], rows[pin:pout + 1]
 
 
 def total(rows):
