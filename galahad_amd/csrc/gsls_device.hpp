@@ -100,7 +100,7 @@ struct DeviceFactor {
   int64_t xs_mr = 0, cs_mr = 0;
   // several right-hand sides through one launch of the single-column kernels (struct Cols in gsls_device.hip):
   // MC_MAX sets of work vectors, the sets mc_s* elements apart
-  static constexpr int MC_MAX = 8;
+  static constexpr int MC_MAX = 16;
   double *mc_xp = nullptr, *mc_xs = nullptr, *mc_cvec = nullptr, *mc_ybuf = nullptr, *mc_part = nullptr;
   int64_t mc_sx = 0, mc_scv = 0;
   int64_t part_elems = 0;
