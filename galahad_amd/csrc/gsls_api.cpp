@@ -302,6 +302,7 @@ int gsls_destroy(void** handle) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     dev_free(h->F);
     dev_free_coo(h->F);
+    h->F.pool.reset();          // (the blocks the pool keeps are freed here, on the handle's device)
     (void)gsls_comm_destroy(h);
     for (auto& ev : h->ev)
       if (ev) (void)hipEventDestroy(ev);

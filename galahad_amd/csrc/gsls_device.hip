@@ -4505,11 +4505,74 @@ __global__ void k_iota(int n, int32_t* __restrict__ a) {
 // =================================================================================================
 // host side: upload of the symbolic data and the per-level launch plan
 // =================================================================================================
+// ---- the handle's block pool (DevPool, gsls_device.hpp) -------------------------------------------------------------------
+DevPool::~DevPool() {
+  for (auto& kv : idle) (void)hipFree(kv.second);
+}
+static thread_local DevPool* tl_pool = nullptr;      // the pool of the handle whose arrays are being (re)built
+struct PoolScope {
+  DevPool* prev;
+  explicit PoolScope(DeviceFactor& F) : prev(tl_pool) {
+    static const bool off = getenv("GSLS_NO_POOL") != nullptr;     // (A/B knob)
+    if (!F.pool) F.pool = std::make_shared<DevPool>();
+    tl_pool = off ? nullptr : F.pool.get();
+  }
+  ~PoolScope() { tl_pool = prev; }
+};
+static size_t pool_class(size_t bytes) {             // next of 8 steps per power of two (<= 12.5 % head-room), >= 512 B
+  size_t c = 512;
+  while (c < bytes) c <<= 1;
+  if (c > 512) {
+    const size_t step = c >> 4;                       // c / 2 < bytes <= c: classes c/2 + k * c/16
+    c = (c >> 1) + ((bytes - (c >> 1) + step - 1) / step) * step;
+  }
+  return c;
+}
+static hipError_t pool_alloc(void** p, size_t bytes) {
+  DevPool* pool = tl_pool;
+  if (!pool || bytes > (size_t(256) << 20)) return hipMalloc(p, bytes);     // (large blocks: exact size, never kept)
+  const size_t c = pool_class(bytes);
+  auto it = pool->idle.find(c);
+  if (it != pool->idle.end()) {
+    *p = it->second;
+    pool->idle.erase(it);
+    pool->idle_bytes -= c;
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(p, c);
+  if (e != hipSuccess && !pool->idle.empty()) {       // out of memory with blocks waiting: give them back and try again
+    for (auto& kv : pool->idle) { (void)hipFree(kv.second); pool->size.erase(kv.second); }
+    pool->idle.clear();
+    pool->idle_bytes = 0;
+    e = hipMalloc(p, c);
+  }
+  if (e == hipSuccess) pool->size[*p] = c;
+  return e;
+}
+// blocks the pool does not know (plain hipMalloc elsewhere) are simply freed; large ones are not kept waiting
+static void pool_free(DeviceFactor& F, void* p) {
+  if (!p) return;
+  DevPool* pool = F.pool.get();
+  if (pool) {
+    auto it = pool->size.find(p);
+    if (it != pool->size.end()) {
+      const size_t c = it->second;
+      if (c <= (size_t(256) << 20) && pool->idle_bytes + c <= (size_t(2) << 30)) {
+        pool->idle.emplace(c, p);
+        pool->idle_bytes += c;
+        return;
+      }
+      pool->size.erase(it);
+    }
+  }
+  (void)hipFree(p);
+}
+
 template <class T>
 static hipError_t upload(T*& dptr, const std::vector<T>& h, hipStream_t st) {
   dptr = nullptr;
   if (h.empty()) return hipSuccess;
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&dptr), h.size() * sizeof(T)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&dptr), h.size() * sizeof(T)));
   return hipMemcpyAsync(dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
 }
 
@@ -4527,14 +4590,14 @@ void dev_free(DeviceFactor& F) {
                   F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wpull2, F.wnont, F.Lf, F.Lb, F.xs, F.gvar,
                   F.disc_tasks, F.disc_arc, F.disc_ddelay, F.disc_dvar, F.disc_pseq, F.disc_pcnt, F.disc_flags, F.disc_ptwo, F.disc_arena,
                   F.disc_scratch, F.disc_list};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  for (void* p : ptrs) pool_free(F, p);
   for (void* p : {static_cast<void*>(F.mc_xp), static_cast<void*>(F.mc_xs), static_cast<void*>(F.mc_cvec),
                   static_cast<void*>(F.mc_ybuf), static_cast<void*>(F.mc_part)})
-    if (p) (void)hipFree(p);
+    pool_free(F, p);
   // the caller's matrix (gsls_set_coo) depends on the pattern only, not on the elimination order: it survives
   // the re-analyses of order repair and learning; dev_free_coo releases it
   DeviceFactor keep;
+  keep.pool = F.pool;
   keep.coo_ne = F.coo_ne; keep.coo_nz = F.coo_nz; keep.nscatter_coo = F.nscatter_coo;
   keep.mv_ptr = F.mv_ptr; keep.mv_src = F.mv_src; keep.rs_ptr = F.rs_ptr; keep.rs_col = F.rs_col;
   keep.rs_src = F.rs_src; keep.coo_val = F.coo_val; keep.valcsc = F.valcsc; keep.rbuf = F.rbuf;
@@ -4585,6 +4648,7 @@ static hipError_t allow_big_lds() {
 }
 
 hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t st) {
+  PoolScope pool_scope(F);
   F.pure_state = false;      // (gperm, D, gvar are rebuilt: dev_factor)
   const int me = F.myrank;
   dev_free(F);
@@ -5109,12 +5173,12 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
         if (unit) F.wstage_unit[k] = wg[F.wstage_begin[k]].tbeg;
       }
       HIPCHK(upload(F.wnont, nont, st));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.Lf), std::max<int64_t>(of, 2) * sizeof(double)));
+      HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.Lf), std::max<int64_t>(of, 2) * sizeof(double)));
       F.Lb = nullptr;       // (one image since round 3: the backward sweep transposes Lf in LDS)
       HIPCHK(hipMemsetAsync(F.Lf, 0, std::max<int64_t>(of, 2) * sizeof(double), st));   // the diagonal slots stay 0
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xs), (std::max(S.n, 1) + 64) * sizeof(double)));
+      HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.xs), (std::max(S.n, 1) + 64) * sizeof(double)));
       HIPCHK(hipMemsetAsync(F.xs, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gvar), (std::max(S.n, 1) + 64) * sizeof(int32_t)));
+      HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.gvar), (std::max(S.n, 1) + 64) * sizeof(int32_t)));
       HIPCHK(hipMemsetAsync(F.gvar, 0, (std::max(S.n, 1) + 64) * sizeof(int32_t), st));
       build_plan(F.planW, [&](int s) { return !waveT[s]; }, all);
       F.wave = true;
@@ -5233,9 +5297,9 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
       for (int p2 = S.sptr[s]; p2 < S.sptr[s + 1]; ++p2) po[p2] = S.owner[s];
     HIPCHK(upload(F.posowner, po, st));
   }
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.ybuf), std::max(S.n, 1) * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.ybuf), std::max(S.n, 1) * sizeof(double)));
   F.part_elems = std::max<int64_t>(part_max, 1) * 64;
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.part), F.part_elems * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.part), F.part_elems * sizeof(double)));
   {
     PullSeg* d1 = nullptr;
     PullTask* d2 = nullptr;
@@ -5282,24 +5346,24 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
     F.cztasks = d;
   }
   F.cvec_elems = S.cmapptr[nn];
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.L), std::max<int64_t>(F.L_elems, 1) * sizeof(double)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.C), std::max<int64_t>(F.C_elems, 1) * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.L), std::max<int64_t>(F.L_elems, 1) * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.C), std::max<int64_t>(F.C_elems, 1) * sizeof(double)));
   // (+ 64 elements / 132 doubles of padding: the wave tier loads [sptr + lane] and [moff + lane] unmasked)
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.D), (2 * int64_t(S.n) + 4 + 132) * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.D), (2 * int64_t(S.n) + 4 + 132) * sizeof(double)));
   HIPCHK(hipMemsetAsync(F.D, 0, (2 * int64_t(S.n) + 4 + 132) * sizeof(double), st));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.gperm), (std::max(S.n, 1) + 64) * sizeof(int32_t)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.gperm), (std::max(S.n, 1) + 64) * sizeof(int32_t)));
   HIPCHK(hipMemsetAsync(F.gperm, 0, (std::max(S.n, 1) + 64) * sizeof(int32_t), st));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec), (std::max<int64_t>(F.cvec_elems, 1) + 64) * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.cvec), (std::max<int64_t>(F.cvec_elems, 1) + 64) * sizeof(double)));
   HIPCHK(hipMemsetAsync(F.cvec, 0, (std::max<int64_t>(F.cvec_elems, 1) + 64) * sizeof(double), st));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.stat), NSTAT * sizeof(int32_t)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.faillist), FAILCAP * sizeof(int32_t)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.fastok), std::max<int64_t>(F.nblk64, 1) * sizeof(int32_t)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tinyskip), std::max(nn, 1)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.stat), NSTAT * sizeof(int32_t)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.faillist), FAILCAP * sizeof(int32_t)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.fastok), std::max<int64_t>(F.nblk64, 1) * sizeof(int32_t)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.tinyskip), std::max(nn, 1)));
   HIPCHK(hipMemsetAsync(F.tinyskip, 0, std::max(nn, 1), st));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tinyfail), FAILCAP * sizeof(int32_t)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.tppflag), std::max(nn, 1)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.tinyfail), FAILCAP * sizeof(int32_t)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.tppflag), std::max(nn, 1)));
   HIPCHK(hipMemsetAsync(F.tppflag, 0, std::max(nn, 1), st));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.hint), std::max(S.n, 1)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.hint), std::max(S.n, 1)));
   HIPCHK(hipMemsetAsync(F.hint, 0, std::max(S.n, 1), st));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
   return hipSuccess;
@@ -5457,6 +5521,7 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
 // task list, rebuilt and uploaded whenever the blacklist grows (a few entries; no re-analysis).
 hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes,
                                   hipStream_t st) {
+  PoolScope pool_scope(F);
   const int nn = S.nnodes;
   std::vector<uint8_t> skip(std::max(nn, 1), 0);
   std::vector<std::vector<int>> per(S.nlevels);
@@ -5512,7 +5577,7 @@ hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std:
   }
   for (void* p2 : {static_cast<void*>(F.bl_ptasks), static_cast<void*>(F.bl_ttasks), F.bl_tctasks, F.bl_pullsegs,
                    F.bl_pulltasks})
-    if (p2) (void)hipFree(p2);
+    pool_free(F, p2);
   F.bl_ptasks = nullptr;
   F.bl_ttasks = nullptr;
   F.bl_tctasks = nullptr;
@@ -5583,8 +5648,7 @@ hipError_t dev_max_abs(int n, const double* d_v, unsigned long long* d_out, hipS
 
 void dev_free_coo(DeviceFactor& F) {
   void* ptrs[] = {F.mv_ptr, F.mv_src, F.rs_ptr, F.rs_col, F.rs_src, F.coo_val, F.valcsc, F.rbuf};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  for (void* p : ptrs) pool_free(F, p);
   F.mv_ptr = F.rs_ptr = nullptr;
   F.mv_src = F.rs_col = F.rs_src = nullptr;
   F.coo_val = F.valcsc = F.rbuf = nullptr;
@@ -5593,6 +5657,7 @@ void dev_free_coo(DeviceFactor& F) {
 
 hipError_t dev_set_coo(DeviceFactor& F, int n, int64_t nzcsc, int64_t ne, const int32_t* row, const int32_t* col,
                        const int32_t* map, hipStream_t st) {
+  PoolScope pool_scope(F);
   dev_free_coo(F);
   // by destination: the caller's entries of every CSC position, in entry order
   std::vector<int64_t> mptr(nzcsc + 1, 0);
@@ -5612,8 +5677,8 @@ hipError_t dev_set_coo(DeviceFactor& F, int n, int64_t nzcsc, int64_t ne, const 
   HIPCHK(upload(F.mv_ptr, mptr, st));
   HIPCHK(upload(F.mv_src, msrc, st));
   F.coo_ne = ne;
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.coo_val), std::max<int64_t>(ne, 1) * sizeof(double)));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.valcsc), std::max<int64_t>(nzcsc, 1) * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.coo_val), std::max<int64_t>(ne, 1) * sizeof(double)));
+  HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.valcsc), std::max<int64_t>(nzcsc, 1) * sizeof(double)));
   F.nscatter_coo = nzcsc;
   if (row && col) {
     // the full symmetric matrix by rows (both triangles), out-of-range entries dropped (sls.f90:4901)
@@ -5675,6 +5740,7 @@ hipError_t dev_residual(DeviceFactor& F, int n, int nrhs, const double* d_x, int
 // node for the blocked kernels to skip them, and per level one node list per plan kind (0: all, 1: the
 // subtrees this rank owns, 2: the top part).
 hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st) {
+  PoolScope pool_scope(F);
   const int nn = S.nnodes;
   std::vector<uint8_t> flag(std::max(nn, 1), 0);
   for (int s : nodes) flag[s] = 1;
@@ -5694,7 +5760,7 @@ hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int
       F.tpp_cnt[which][l] = int(list.size()) - F.tpp_begin[which][l];
     }
   }
-  if (F.tpplist) (void)hipFree(F.tpplist);
+  pool_free(F, F.tpplist);
   F.tpplist = nullptr;
   HIPCHK(upload(F.tpplist, list, st));
   HIPCHK(hipMemcpyAsync(F.tppflag, flag.data(), flag.size(), hipMemcpyHostToDevice, st));
@@ -5704,11 +5770,12 @@ hipError_t dev_set_tpp(const Symbolic& S, DeviceFactor& F, const std::vector<int
 // arena of the L11^-T blocks the Cholesky kernels exchange (one 64 x 64 block per 64 pivots)
 static hipError_t ensure_linv(DeviceFactor& F) {
   if (F.Linv) return hipSuccess;
-  return hipMalloc(reinterpret_cast<void**>(&F.Linv), std::max<int64_t>(F.nblk64, 1) * NB * NB * sizeof(double));
+  return pool_alloc(reinterpret_cast<void**>(&F.Linv), std::max<int64_t>(F.nblk64, 1) * NB * NB * sizeof(double));
 }
 
 hipError_t dev_discover(const Symbolic& S, DeviceFactor& F, const double* d_val, double small, double u, hipStream_t st,
                         std::vector<int32_t>& seq, std::vector<uint8_t>& two, int& status, int& ndelayed) {
+  PoolScope pool_scope(F);
   const int nn = S.nnodes, n = S.n;
   status = 1;
   ndelayed = 0;
@@ -5774,14 +5841,14 @@ hipError_t dev_discover(const Symbolic& S, DeviceFactor& F, const double* d_val,
     F.disc_tasks = d;
     HIPCHK(upload(F.disc_arc, arc, st));
     HIPCHK(upload(F.disc_list, dl, st));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_ddelay), size_t(nn) * sizeof(int32_t)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_dvar), size_t(std::max<int64_t>(voff, 1)) * sizeof(int32_t)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_pseq), size_t(std::max<int64_t>(poff, 1)) * sizeof(int32_t)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_ptwo), size_t(std::max<int64_t>(poff, 1))));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_pcnt), size_t(nn) * sizeof(int32_t)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_flags), 4 * sizeof(int32_t)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_arena), size_t(std::max<int64_t>(off, 1)) * sizeof(double)));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.disc_scratch), size_t(std::max<int64_t>(woff, 1)) * sizeof(double)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_ddelay), size_t(nn) * sizeof(int32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_dvar), size_t(std::max<int64_t>(voff, 1)) * sizeof(int32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_pseq), size_t(std::max<int64_t>(poff, 1)) * sizeof(int32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_ptwo), size_t(std::max<int64_t>(poff, 1))));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_pcnt), size_t(nn) * sizeof(int32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_flags), 4 * sizeof(int32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_arena), size_t(std::max<int64_t>(off, 1)) * sizeof(double)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.disc_scratch), size_t(std::max<int64_t>(woff, 1)) * sizeof(double)));
     F.disc_host.assign(dt.size() * 2, 0);        // (poff, mcap) per front for the read-back
     for (int s = 0; s < nn; ++s) { F.disc_host[2 * s] = dt[s].poff; F.disc_host[2 * s + 1] = dt[s].mcap; }
   }
@@ -6145,8 +6212,8 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
       if (!F.xp_mr) {
         F.xs_mr = ((int64_t(S.n) + 64 + 15) / 16) * 16;
         F.cs_mr = ((std::max<int64_t>(F.cvec_elems, 1) + 64 + 15) / 16) * 16;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp_mr), 8 * F.xs_mr * sizeof(double)));
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.cvec_mr), 8 * F.cs_mr * sizeof(double)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.xp_mr), 8 * F.xs_mr * sizeof(double)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.cvec_mr), 8 * F.cs_mr * sizeof(double)));
         HIPCHK(hipMemsetAsync(F.xp_mr, 0, 8 * F.xs_mr * sizeof(double), st));
         HIPCHK(hipMemsetAsync(F.cvec_mr, 0, 8 * F.cs_mr * sizeof(double), st));
       }
@@ -6165,7 +6232,7 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
       for (int k = 1; k < 4; ++k) HIPCHK(hipEventRecord(ev[k], st));
   }
   if (F.nrhs_cap < 1) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));
     HIPCHK(hipMemsetAsync(F.xp, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
     F.nrhs_cap = 1;
   }
@@ -6206,12 +6273,12 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
         F.mc_sx = ((int64_t(S.n) + 64 + 15) / 16) * 16;
         F.mc_scv = ((std::max<int64_t>(F.cvec_elems, 1) + 64 + 15) / 16) * 16;
         for (double** q : {&F.mc_xp, &F.mc_xs, &F.mc_ybuf}) {
-          HIPCHK(hipMalloc(reinterpret_cast<void**>(q), M * F.mc_sx * sizeof(double)));
+          HIPCHK(pool_alloc(reinterpret_cast<void**>(q), M * F.mc_sx * sizeof(double)));
           HIPCHK(hipMemsetAsync(*q, 0, M * F.mc_sx * sizeof(double), st));
         }
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.mc_cvec), M * F.mc_scv * sizeof(double)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.mc_cvec), M * F.mc_scv * sizeof(double)));
         HIPCHK(hipMemsetAsync(F.mc_cvec, 0, M * F.mc_scv * sizeof(double), st));
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.mc_part), M * std::max<int64_t>(F.part_elems, 64) * sizeof(double)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.mc_part), M * std::max<int64_t>(F.part_elems, 64) * sizeof(double)));
       }
       static const int cols_xcd = getenv("GSLS_COLS_XCD") ? atoi(getenv("GSLS_COLS_XCD")) : 1;
       const Cols cs{R, cols_xcd, F.mc_sx, F.mc_sx, F.mc_scv, F.mc_sx, std::max<int64_t>(F.part_elems, 64), int64_t(ldx)};
@@ -6298,7 +6365,7 @@ hipError_t dev_shard_solve(const Symbolic& S, DeviceFactor& F, int phase, bool p
   if (!F.sharded) return hipErrorInvalidValue;
   if (S.n == 0) return hipSuccess;
   if (F.nrhs_cap < 1) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));
     HIPCHK(hipMemsetAsync(F.xp, 0, (std::max(S.n, 1) + 64) * sizeof(double), st));
     F.nrhs_cap = 1;
   }

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
+#include <memory>
+#include <unordered_map>
 #include <vector>
 
 #include "gsls_internal.hpp"
@@ -64,7 +67,19 @@ struct BlLevel {
   int pbeg = 0, np = 0, tbeg = 0, nt = 0, tcbeg = 0, ntc = 0, rows = 0, pullbeg = 0, npull = 0;
 };
 
+// Device blocks of one handle, kept across the re-analyses of a factorization (order repair, learning, discovery rebuild
+// some sixty arrays each time): a freed block waits here, by size class, for the next upload of that size instead of
+// going through hipFree (a device-wide synchronisation each) and hipMalloc.  Per handle, so a block is only ever reused
+// by work that is enqueued later on the handle's own stream.
+struct DevPool {
+  std::multimap<size_t, void*> idle;            // size class -> block
+  std::unordered_map<void*, size_t> size;      // every block handed out or idle
+  size_t idle_bytes = 0;
+  ~DevPool();
+};
+
 struct DeviceFactor {
+  std::shared_ptr<DevPool> pool;                // (survives dev_free; released with the handle)
   // symbolic (uploaded once per analyse)
   NodeDesc* nodes = nullptr;
   int32_t* rlist = nullptr;
