@@ -2991,25 +2991,38 @@ struct WFwdFlat {
   double rhs;
   int gp, pr;
 };
-template <bool APPLY_D>
+// GATHER: the right-hand side comes from the CALLER's vector (variable order) through invp -- its index is the first load
+// issued, so that the dependent load can go out while the image is still arriving (results return in order: waiting for
+// the oldest load waits for nothing else) -- instead of from the permuted copy xp: the k_permute_in launch disappears
+// for the fronts of the bottom stage's narrow launch, which also permutes the remaining 3 % of the positions for the
+// launches behind it (trailing workgroups, k_wsolve_fwd).
+template <bool APPLY_D, bool GATHER = false>
 __device__ __forceinline__ void wave_fwd_issue(const WTask& t, int lane, WFwdFlat<APPLY_D>& q, const double* __restrict__ Lf,
                                                const double* __restrict__ D, const int32_t* __restrict__ gperm,
-                                               const int32_t* __restrict__ cmap, const double* __restrict__ xp) {
+                                               const int32_t* __restrict__ cmap, const double* __restrict__ xp,
+                                               const int32_t* __restrict__ invp = nullptr,
+                                               const double* __restrict__ xin = nullptr) {
   const int m = t.m, n = t.n;
   const int npair = (n + 1) >> 1;
   const int nbytes = 16 * (npair * (m - 1) - npair * (npair - 1));
   const int oob = int(0x80000000);
+  int iv = 0;
+  if (GATHER) iv = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(invp + t.sptr, n * 4), lane * 4, 0, 0);
   const __amdgpu_buffer_rsrc_t rs = wave_rsrc(Lf + t.lfoff, nbytes);
 #pragma unroll
   for (int c = 0; c < WIMG_CHUNKS; ++c) {
     q.ch[c] = double2_t{0.0, 0.0};
     if (c < 2 || c * 1024 < nbytes) q.ch[c] = wave_ld_f64x2<GSLS_WS_NT_F>(rs, lane * 16, c * 1024);   // (uniform)
   }
-  q.rhs = wave_ld_f64(wave_rsrc(xp + t.sptr, n * 8), lane * 8);
+  if (!GATHER) q.rhs = wave_ld_f64(wave_rsrc(xp + t.sptr, n * 8), lane * 8);
   q.gp = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(gperm + t.sptr, n * 4), lane * 4, 0, 0);
   q.pr = __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(cmap + t.moff, (m - n) * 4), lane >= n ? (lane - n) * 4 : oob, 0, 0);
   q.dd = double2_t{0.0, 0.0};
   if (APPLY_D) q.dd = wave_ld_f64x2(wave_rsrc(D + 2 * int64_t(t.sptr), n * 16), lane * 16, 0);
+  if (GATHER) {
+    const double v = xin[lane < n ? iv : 0];     // (iv = 0 from the descriptor for the lanes that are not pivots)
+    q.rhs = lane < n ? v : 0.0;
+  }
 }
 // arrival: through LDS to the lane = row, register = column pair form the recurrence wants
 template <bool APPLY_D>
@@ -3437,14 +3450,32 @@ __device__ __forceinline__ WTask wave_task(const WTask* __restrict__ tasks, int 
 // the arithmetic: with a launch per column (CG = 1, grid x R) eight columns read the 170 MB image eight times.
 // (Tried on top and dropped: the next front's loads in flight during this front's CG recurrences -- 0.60 -> 0.62 ms
 // for eight columns.)
-template <bool APPLY_D, bool NARROW, bool FLAT = false, int CG = 1>
+struct WGather {                 // GATHER launches: the caller's right-hand side, invp, and the positions this launch permutes
+  const double* xin;             // for the launches behind it (workgroups from `nblk` on)
+  const int32_t* invp;
+  const int32_t* list;
+  int cnt, nblk;
+};
+template <bool APPLY_D, bool NARROW, bool FLAT = false, int CG = 1, bool GATHER = false>
 __global__ void __launch_bounds__(256)
 k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restrict__ tasks,
              const double* __restrict__ Lf, const double* __restrict__ D, const int32_t* __restrict__ gperm,
              const int32_t* __restrict__ cmap, const int32_t* __restrict__ gth_ptr,
              const int64_t* __restrict__ gth_src, double* __restrict__ xp, double* __restrict__ slotv,
-             double* __restrict__ cvec, Cols cs, const int32_t* __restrict__ pull2, int unit_tbeg, int wimg_units) {
+             double* __restrict__ cvec, Cols cs, const int32_t* __restrict__ pull2, int unit_tbeg, int wimg_units,
+             WGather wg = WGather{nullptr, nullptr, nullptr, 0, 0}) {
   static_assert(CG == 1 || (NARROW && FLAT), "column groups: narrow flat launches only");
+  static_assert(!GATHER || (NARROW && FLAT && CG == 1), "fused input permutation: the single-column narrow flat launch");
+  if constexpr (GATHER) {
+    if (int(blockIdx.x) >= wg.nblk) {       // trailing workgroups: xp = P x for the positions of every other launch
+      const int i = (int(blockIdx.x) - wg.nblk) * 256 + int(threadIdx.x);
+      if (i < wg.cnt) {
+        const int pos = wg.list[i];
+        xp[pos] = wg.xin[wg.invp[pos]];
+      }
+      return;
+    }
+  }
   constexpr int AS = (NARROW && FLAT) ? WACC_NARROW : 64;
   // accumulators: a row per LDS slot + a spare row (64 wide) for the masked lanes.  CG = 1: WSLOT rows, static; column
   // groups: the launch's deepest slot (wimg_units carries it), CG sets per wave in dynamic LDS -- what decides how many
@@ -3489,7 +3520,7 @@ k_wsolve_fwd(const WGroup* __restrict__ groups, int ngroup, const WTask* __restr
       if constexpr (FLAT) {
         __shared__ __attribute__((aligned(16))) double2_t wimg[4][WIMG_BYTES / 16];
         WFwdFlat<APPLY_D> Q;
-        wave_fwd_issue<APPLY_D>(ta, lane, Q, Lf, D, gperm, cmap, xp);
+        wave_fwd_issue<APPLY_D, GATHER>(ta, lane, Q, Lf, D, gperm, cmap, xp, wg.invp, wg.xin);
 #pragma unroll
         for (int c = 1; c < CG; ++c) rhsx[c] = wave_ld_f64(wave_rsrc(xp + c * cs.sx + ta.sptr, ta.n * 8), lane * 8);
         wave_fwd_arrive<APPLY_D>(ta, lane, Q, A, wimg[wave]);
@@ -4589,7 +4620,7 @@ void dev_free(DeviceFactor& F) {
                   F.biggemv, F.ybuf, F.part, F.Linv, F.stasks, F.gth_ptr, F.gth_src, F.fastok, F.hint, F.tinyskip, F.tinyfail, F.bl_ptasks, F.bl_ttasks, F.bl_tctasks, F.segC, F.segV, F.segZ, F.posowner, F.tppflag, F.tpplist,
                   F.cztasks, F.gdst, F.gbeg, F.gsrc, F.aloc, F.asrc_wg, F.adst_wg, F.bl_pullsegs, F.bl_pulltasks, F.wtasks, F.wgroups, F.wpacks, F.wgth_ptr, F.wgth_src, F.wpull2, F.wnont, F.Lf, F.Lb, F.xs, F.gvar,
                   F.disc_tasks, F.disc_arc, F.disc_ddelay, F.disc_dvar, F.disc_pseq, F.disc_pcnt, F.disc_flags, F.disc_ptwo, F.disc_arena,
-                  F.disc_scratch, F.disc_list};
+                  F.disc_scratch, F.disc_list, F.wperm_list};
   for (void* p : ptrs) pool_free(F, p);
   for (void* p : {static_cast<void*>(F.mc_xp), static_cast<void*>(F.mc_xs), static_cast<void*>(F.mc_cvec),
                   static_cast<void*>(F.mc_ybuf), static_cast<void*>(F.mc_part)})
@@ -5046,6 +5077,21 @@ hipError_t dev_upload_symbolic(const Symbolic& S, DeviceFactor& F, hipStream_t s
           for (int ci = S.cptr[s]; ci < S.cptr[s + 1]; ++ci) t.flags |= closed[S.clist[ci]] ? WT_PULL : WT_INT;
           wp[ti] = WPack{S.loff[s], s, 0};
         }
+      }
+      // fused input permutation (k_wsolve_fwd<.., GATHER>): every position that is NOT a pivot of a front in the narrow
+      // runs of stage 0 -- those fronts fetch their right-hand side through invp themselves
+      {
+        std::vector<char> own(std::max(S.n, 1), 0);
+        if (nstage > 0)
+          for (int r = F.wstage_begin[0]; r < F.wstage_begin[0] + F.wstage_narrow[0]; ++r)
+            for (int64_t ti = wg[r].tbeg; ti < int64_t(wg[r].tbeg) + wg[r].tcnt; ++ti)
+              for (int c = 0; c < wt[ti].n; ++c) own[wt[ti].sptr + c] = 1;
+        std::vector<int32_t> rest;
+        for (int i = 0; i < S.n; ++i)
+          if (!own[i]) rest.push_back(i);
+        F.wperm_cnt = int(rest.size());
+        rest.push_back(0);
+        HIPCHK(upload(F.wperm_list, rest, st));
       }
       // deepest LDS slot the narrow runs of each stage use (the column-group launches size their accumulators by it)
       F.wstage_ndepth.assign(nstage, 1);
@@ -5947,6 +5993,18 @@ hipError_t dev_factor(const Symbolic& S, DeviceFactor& F, bool posdef, const dou
   return hipGetLastError();
 }
 
+static bool ws_flat_on() {
+  static const bool on = !(getenv("GSLS_WS_FLAT") && atoi(getenv("GSLS_WS_FLAT")) == 0);   // (A/B knob)
+  return on;
+}
+// the bottom stage's narrow launch reads the right-hand side from the caller's vector itself (no k_permute_in): whole
+// solves of one column on the wave tier, no scaling vector
+static bool can_fuse_input(const DeviceFactor& F, int job, bool scaled, int R) {
+  static const bool off = getenv("GSLS_NO_FUSE_IN") != nullptr;
+  return !off && F.wave && job == GSLS_SOLVE_JOB_ALL && !scaled && R == 1 && ws_flat_on() && F.wperm_list != nullptr &&
+         !F.wstage_narrow.empty() && F.wstage_narrow[0] > 0 && !(F.wtail_k0 == 0);
+}
+
 // wave: the wave tier (LDL^T fronts of at most 64 rows) runs beside `plan`, which then holds the other fronts only;
 // xin / xout: the caller's vector when the tier reads the right-hand side / writes the solution itself
 template <bool POSDEF>
@@ -5975,7 +6033,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   double* slotv = (wave && do_fwd && do_bwd) ? w_xs : nullptr;
   // (experiment knob: unused dynamic LDS per workgroup of the narrow wave kernels = fewer waves per CU)
   static const size_t ws_pad = getenv("GSLS_WS_LDSPAD") ? size_t(atoi(getenv("GSLS_WS_LDSPAD"))) : 0;
-  static const bool ws_flat = !(getenv("GSLS_WS_FLAT") && atoi(getenv("GSLS_WS_FLAT")) == 0);   // (A/B knob)
+  const bool ws_flat = ws_flat_on();
   // columns per wave in the narrow flat launches (several right-hand sides): 4, 2 or 1, whatever divides R
   static const int colgrp_max = getenv("GSLS_WS_COLGRP") ? atoi(getenv("GSLS_WS_COLGRP")) : 4;
   const int colgrp = (R > 1 && colgrp_max >= 4 && R % 4 == 0) ? 4 : (R > 1 && colgrp_max >= 2 && R % 2 == 0) ? 2 : 1;
@@ -6056,6 +6114,13 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
   if (do_fwd && wave) {
     for (int k = 0; k < ktail; ++k) {                       // stages of small subtrees, bottom-up
       const int nar = ahead ? F.wstage_narrow[k] : 0;
+      if (k == 0 && xin && nar > 0) {        // (dev_solve asked can_fuse_input: fuse_d, ahead, one column, flat)
+        const int nblk = (nar + 3) / 4;
+        const WGather wgi{xin, F.invp, F.wperm_list, F.wperm_cnt, nblk};
+        hipLaunchKernelGGL((k_wsolve_fwd<true, true, true, 1, true>), dim3(nblk + (F.wperm_cnt + 255) / 256), dim3(256), ws_pad, st,
+                           wgr + F.wstage_begin[0], nar, wtk, F.Lf, F.D, F.gperm, F.cmap, F.wgth_ptr, F.wgth_src, xp, slotv,
+                           w_cvec, cs, F.wpull2, -1, F.wimg_units, wgi);
+      } else
       wave_fwd(F.wstage_begin[k], nar, true, -1, k < int(F.wstage_ndepth.size()) ? F.wstage_ndepth[k] : WSLOT);
       wave_fwd(F.wstage_begin[k] + nar, F.wstage_cnt[k] - nar, false, nar == 0 ? F.wstage_unit[k] : -1);
     }
@@ -6255,10 +6320,12 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
     hipEvent_t* evr = (r == r0) ? ev : nullptr;
     hipError_t e;
     if (R == 1) {
-      hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
-                         scale_in ? d_scale : nullptr, F.xp);
+      const bool fuse_in = wave && can_fuse_input(F, job, d_scale != nullptr, 1);
+      if (!fuse_in)
+        hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
+                           scale_in ? d_scale : nullptr, F.xp);
       e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, evr)
-          : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, nullptr,
+          : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, fuse_in ? x : nullptr,
                                        fuse_out ? x : nullptr, scale_out ? d_scale : nullptr)
                  : solve_sweeps<false>(S, F, F.plan, job, F.xp, st, evr);
       if (e != hipSuccess) return e;

@@ -178,6 +178,8 @@ struct DeviceFactor {
   int64_t disc_pcap = 0;
   int wimg_units = 64;            // LDS staging area per wave of the wide backward launches (16-byte units)
   int32_t* wpull2 = nullptr;      // dense form of the gather lists for fronts with at most two sources per row
+  int32_t* wperm_list = nullptr;  // positions the bottom stage's gather launch permutes for the launches behind it
+  int wperm_cnt = 0;
   bool pure_state = false;        // the last factorization pass ran on the wave-per-front kernels only (dev_factor)
   std::vector<int> wstage_ndepth; // per stage: LDS slots its narrow runs use (1 + the deepest myslot / pslot)
   std::vector<int> wstage_unit;   // per stage: first task if every run is one front in task order, else -1
