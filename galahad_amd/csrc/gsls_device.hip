@@ -5459,7 +5459,15 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
       } else {
       int beg = lp.tf_begin, cnt = 0, maxm = 0;
       static const int narrow_max = getenv("GSLS_NARROW_MAX") ? atoi(getenv("GSLS_NARROW_MAX")) : 2048;
-      const bool narrow = lp.tf_cnt <= narrow_max;
+      // ... and up to 16 384 fronts when the classes present are neighbours (24 | 28, 28 | 32, ...): one launch of the wider
+      // body costs the narrower fronts ~1.3x their arithmetic, two launches cost the level a second ramp-up and tail
+      // (metric workload: 0.696 -> 0.675 ms per step; a span of two classes measures the same, three is back to 0.687)
+      static const int merge_max = getenv("GSLS_MERGE_MAX") ? atoi(getenv("GSLS_MERGE_MAX")) : 16384;
+      static const int merge_span = getenv("GSLS_MERGE_SPAN") ? atoi(getenv("GSLS_MERGE_SPAN")) : 1;
+      int clo = TINY_CLASSES, chi = -1;
+      for (int c2 = 0; c2 < TINY_CLASSES; ++c2)
+        if (lp.tf_cls_cnt[c2] > 0) { clo = std::min(clo, c2); chi = std::max(chi, c2); }
+      const bool narrow = lp.tf_cnt <= narrow_max || (lp.tf_cnt <= merge_max && chi - clo <= merge_span && chi <= 3);
       for (int cls = 0; cls < TINY_CLASSES; ++cls) {
         cnt += lp.tf_cls_cnt[cls];
         maxm = std::max(maxm, lp.tf_cls_maxm[cls]);
