@@ -8,7 +8,10 @@ rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # wave-per-front kernels only no longer launches k_iota, the old marker)
 names=[r['Kernel_Name'] for r in rows]
 def is_solve(n): return any(t in n for t in ('k_wsolve_','k_solve_','k_permute_out','k_big_','k_permute_in'))
-pin=max(i for i,n in enumerate(names) if 'k_permute_in' in n)
+end=max(i for i,n in enumerate(names) if is_solve(n))          # last solve kernel of the run
+pin=end
+while pin>0 and (is_solve(names[pin-1]) or 'copyBuffer' in names[pin-1]): pin-=1   # first kernel of that solve (whole solves
+                                                                # read the right-hand side themselves: no k_permute_in)
 a=pin-1
 while a>=0 and not is_solve(names[a]): a-=1
 seg=rows[a+1:]

@@ -17,12 +17,15 @@ def split(rows):
     """last step: factorization = k_iota .. before k_permute_in; solve sweep = k_permute_in .. the last solve kernel
     (k_permute_out, or the wave tier's last backward launch, which writes the caller's vector itself)"""
     names = [r['Kernel_Name'] for r in rows]
-    pin = max(i for i, n in enumerate(names) if 'k_permute_in' in n)
-    pout = max(i for i, n in enumerate(names) if i >= pin and ('k_permute_out' in n or 'k_wsolve_bwd' in n or 'k_solve_bwd' in n))
-    # the factorization starts right after the solve kernels of the step before (k_iota, the old marker, is not launched
-    # by a refactorization that runs on the wave-per-front kernels only)
+
     def is_solve(n):
         return any(t in n for t in ('k_wsolve_', 'k_solve_', 'k_permute_out', 'k_big_', 'k_permute_in'))
+    pout = max(i for i, n in enumerate(names) if is_solve(n))
+    pin = pout
+    while pin > 0 and is_solve(names[pin - 1]):     # (whole solves read the right-hand side themselves: no k_permute_in)
+        pin -= 1
+    # the factorization starts right after the solve kernels of the step before (k_iota, the old marker, is not launched
+    # by a refactorization that runs on the wave-per-front kernels only)
     a = pin - 1
     while a >= 0 and not is_solve(names[a]):
         a -= 1
