@@ -41,6 +41,10 @@ __device__ unsigned long long g_stamps[64];
 #define STAMPN(i) do {} while (0)
 #endif
 
+#ifndef GSLS_FW_LDSB
+#define GSLS_FW_LDSB 0
+#endif
+
 #define HIPCHK(call)                    \
   do {                                  \
     hipError_t e__ = (call);            \
@@ -734,6 +738,9 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLis
              double* __restrict__ Lf, double* __restrict__ Lbk, int tri, int skip_hinted) {
   extern __shared__ __attribute__((aligned(16))) double fsh[];
   __shared__ double psh[WPB][NC];     // per wave: the pivots d_k (for L*D)
+#if GSLS_FW_LDSB
+  __shared__ __attribute__((aligned(16))) double ush[WPB][64];    // per wave: the pivot column, for its broadcasts
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ti = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (ti >= ntask) return;
@@ -772,12 +779,30 @@ k_front_wave(const TinyFrontTask* __restrict__ tasks, int ntask, const GatherLis
       const double own = v[j] * rd;
       if (lane > j && lane < m && !(fabs(own) <= inv_u)) bad = true;   // threshold test, whole column
       const double um = v[j];
+#if GSLS_FW_LDSB
+      // EXPERIMENT (-DGSLS_FW_LDSB=1, off): the pivot column through LDS -- one 16-byte broadcast read per TWO columns on the
+      // LDS port instead of four v_readlane_b32 on the VALU port (600 of ~1700 instructions per 24-column front are these
+      // broadcasts).  Same operands, same FMAs, same bits -- and 0.69 against 0.67 ms per step on the metric workload
+      // (round 3; round 2 measured "no difference" on this kernel's predecessor): the write -> read round trip through LDS
+      // sits on every column's critical path.
+      ush[wave][lane] = um;
+      typedef double double2_t __attribute__((ext_vector_type(2)));
+      const double2_t* u2 = reinterpret_cast<const double2_t*>(ush[wave]);
+#pragma unroll
+      for (int p2 = (j + 1) >> 1; p2 < NC / 2; ++p2) {
+        if (NC > 32 && 2 * p2 >= 32 && 2 * p2 >= n) continue;
+        const double2_t l2 = u2[p2];
+        if (2 * p2 > j) v[2 * p2] = fma(-own, l2.x, v[2 * p2]);
+        v[2 * p2 + 1] = fma(-own, l2.y, v[2 * p2 + 1]);
+      }
+#else
 #pragma unroll
       for (int k = j + 1; k < NC; ++k) {
         if (NC > 32 && k >= 32 && k >= n) continue;      // (uniform; the wide variant skips its idle tail)
         const double lkj = readlane_f64(um, k);
         v[k] = fma(-own, lkj, v[k]);
       }
+#endif
       v[j] = (lane == j) ? 1.0 : own;
       if (lane == j) myd0 = rd;
       if (lane == 0) ps[j] = d;
