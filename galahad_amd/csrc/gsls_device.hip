@@ -6197,7 +6197,10 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
                            F.bignodes + lp.big_begin, F.gperm, w_ybuf, xp, 0, cs);
       }
     }
-  if (ev) HIPCHK(hipEventRecord(ev[1], st));
+  // the events between the phases cost the sweep ~10 us (a barrier packet each, the queue drains around them): only on
+  // request; otherwise ev[0] .. ev[3] bracket the whole sweep
+  static const bool phase_events = getenv("GSLS_SOLVE_PHASES") != nullptr;
+  if (ev && phase_events) HIPCHK(hipEventRecord(ev[1], st));
   if (fuse_d) {
     if (F.wnont_cnt > 0)
       hipLaunchKernelGGL(k_solve_diag_nodes, dim3((F.wnont_cnt) * R), dim3(256), 0, st, F.nodes, F.wnont, F.D, F.gperm, xp, cs);
@@ -6208,7 +6211,7 @@ static hipError_t solve_sweeps(const Symbolic& S, DeviceFactor& F, const std::ve
       hipLaunchKernelGGL(k_solve_diag_owned, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, F.D, F.gperm,
                          F.posowner, diag_sel, xp);
   }
-  if (ev) HIPCHK(hipEventRecord(ev[2], st));
+  if (ev && phase_events) HIPCHK(hipEventRecord(ev[2], st));
   if (do_bwd)
     for (int l = S.nlevels - 1; l >= 0; --l) {
       const LevelPlan& lp = plan[l];
@@ -6326,8 +6329,10 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
                            scale_out ? d_scale : nullptr, d_x + int64_t(r0 + c) * ldx);
       r0 += R;
     }
-    if (ev && r0 >= nrhs && r0 > 0)        // (no single column follows: the phase events bracket the blocked sweeps)
-      for (int k = 1; k < 4; ++k) HIPCHK(hipEventRecord(ev[k], st));
+    if (ev && r0 >= nrhs && r0 > 0) {      // (no single column follows: the events bracket the blocked sweeps)
+      static const bool phase_events = getenv("GSLS_SOLVE_PHASES") != nullptr;
+      for (int k = phase_events ? 1 : 3; k < 4; ++k) HIPCHK(hipEventRecord(ev[k], st));
+    }
   }
   if (F.nrhs_cap < 1) {
     HIPCHK(pool_alloc(reinterpret_cast<void**>(&F.xp), (std::max(S.n, 1) + 64) * sizeof(double)));

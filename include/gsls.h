@@ -332,8 +332,10 @@ int gsls_refine_order(void* handle, const double* val, gsls_inform* inform);
  * optimistic kernels, blocks redone by the complete-pivoting kernel, tiny fronts kept off the wave-per-front kernel */
 int gsls_get_factor_stats(void* handle, int32_t* fast_blocks, int32_t* pivoted_blocks, int32_t* tiny_blacklist);
 
-/* stream the handle launches on (hipStream_t as void*), and per-phase kernel timing of the last
- * solve measured with HIP events on that stream (seconds); used by bench.py's roofline block. */
+/* stream the handle launches on (hipStream_t as void*), and kernel timing of the last solve measured with HIP events
+ * on that stream (seconds); used by bench.py's roofline block.  The whole sweep comes back in *fwd (*diag = *bwd = 0):
+ * events BETWEEN the phases cost the sweep ~10 us and are recorded only when GSLS_SOLVE_PHASES is set in the
+ * environment -- then the three values are the forward, diagonal and backward parts. */
 void* gsls_get_stream(void* handle);
 int gsls_last_solve_kernel_seconds(void* handle, double* fwd, double* diag, double* bwd);
 

@@ -1,6 +1,7 @@
 """Is the bottom stage of the solve bound by latency (time ~ 1 / waves per CU) or by the memory system (time constant)?
 GSLS_WS_LDSPAD adds unused dynamic LDS to the narrow wave kernels: 0 -> 20 waves per CU, 22000 -> 16, 35000 -> 12, 40000 -> 8."""
 import sys, os, subprocess
+import os; os.environ.setdefault("GSLS_SOLVE_PHASES", "1")   # forward / backward separately (events between the phases)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
 import sys, os, ctypes as C
