@@ -298,16 +298,11 @@ def main():
         f = lib.gsls_factor_dev(s.handle, 1 if posdef else 0, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts),
                                 C.byref(ginf))
         assert f >= 0, f
-        # the right-hand side is copied on the library's own stream (the handle's, behind the factorization): no host
+        # right-hand side in d_rhs (kept), solution into d_x: gsls_solve_dev_rhs reads the right-hand side where it is (the
+        # LDL^T wave tier gathers it anyway) or copies it on the handle's own stream -- no copy launched from here, no host
         # synchronisation between the factorization and the solve
-        hs = lib.gsls_get_stream(s.handle)
-        if hs:
-            with torch.cuda.stream(torch.cuda.ExternalStream(hs)):
-                d_x.copy_(d_rhs, non_blocking=True)
-        else:
-            d_x.copy_(d_rhs)
-            torch.cuda.current_stream().synchronize()
-        f = lib.gsls_solve_dev(s.handle, 0, 1, C.c_void_p(d_x.data_ptr()), n, C.byref(s.opts), C.byref(ginf))
+        f = lib.gsls_solve_dev_rhs(s.handle, 0, 1, C.c_void_p(d_rhs.data_ptr()), C.c_void_p(d_x.data_ptr()), n,
+                                   C.byref(s.opts), C.byref(ginf))
         assert f >= 0, f
 
     # the first factorization of an indefinite matrix repairs the elimination order (one-off, like analyse)

@@ -59,6 +59,8 @@ SIGNATURES = {
                                 C.POINTER(Inform)]),
     "gsls_solve": (C.c_int, [C.c_void_p, i32, i32, C.c_void_p, i32, C.POINTER(Options),
                              C.POINTER(Inform)]),
+    "gsls_solve_dev_rhs": (C.c_int, [C.c_void_p, i32, i32, C.c_void_p, C.c_void_p, i32, C.POINTER(Options),
+                                     C.POINTER(Inform)]),
     "gsls_solve_dev": (C.c_int, [C.c_void_p, i32, i32, C.c_void_p, i32, C.POINTER(Options),
                                  C.POINTER(Inform)]),
     "gsls_enquire_posdef": (C.c_int, [C.c_void_p, p_f64, C.POINTER(Inform)]),

@@ -1337,7 +1337,7 @@ int gsls_residual(void* handle, int32_t nrhs, const double* x, int32_t ldx, cons
 }
 
 static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool on_device,
-                        gsls_inform* inform);
+                        gsls_inform* inform, const double* b_dev = nullptr);
 
 // SLS_solve_ir (sls.f90:4770-4949) with every vector resident in HBM: b in, x out, nothing else crosses the bus
 int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double residual_absolute,
@@ -1406,7 +1406,7 @@ int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double resid
 }
 
 static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool on_device,
-                        gsls_inform* inform) {
+                        gsls_inform* inform, const double* b_dev) {
   gsls_inform local;
   if (!inform) inform = &local;
   if (!h || !h->analysed || !h->factored) {
@@ -1424,6 +1424,11 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
   if (h->comm && h->comm_ranks > 1) {
     // one rank of a sharded system: full solves only, column by column, the whole solution on every rank
     if (job != GSLS_SOLVE_JOB_ALL) return inform->flag = GSLS_ERROR_JOB_OOR;
+    if (b_dev && b_dev != x && on_device) {
+      DeviceGuard g0(h->device);
+      hipError_t e0 = hipMemcpyAsync(x, b_dev, (size_t(ldx) * (nrhs - 1) + S.n) * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+      if (e0 != hipSuccess) return fail_hip(h, inform, e0);
+    }
     for (int c = 0; c < nrhs; ++c) {
       double* xc = x + int64_t(c) * ldx;
       int f = on_device ? gsls_comm_solve_dev(h, xc, inform) : gsls_comm_solve(h, xc, inform);
@@ -1451,7 +1456,8 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
     if (e != hipSuccess) return fail_hip(h, inform, e);
     d_x = F.xhost;
   }
-  e = dev_solve(S, F, h->posdef, job, nrhs, d_x, ldx, h->have_scale ? F.scale : nullptr, h->stream, h->ev);
+  e = dev_solve(S, F, h->posdef, job, nrhs, d_x, ldx, h->have_scale ? F.scale : nullptr, h->stream, h->ev,
+                on_device ? b_dev : nullptr);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   if (!on_device) {
     e = hipMemcpyAsync(x, F.xhost, xelems * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -1474,6 +1480,12 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
   if (getenv("GSLS_DEBUG")) fprintf(stderr, "[gsls] solve job %d nrhs %d: %.3f ms\n", job, nrhs, inform->time_solve * 1e3);
   inform->solve_bytes = 2 * 8 * S.num_factor + (h->posdef ? 0 : 16 * int64_t(S.n)) + 32 * int64_t(S.n);
   return inform->flag;
+}
+
+int gsls_solve_dev_rhs(void* handle, int32_t job, int32_t nrhs, const double* d_b, double* d_x, int32_t ldx,
+                       const gsls_options*, gsls_inform* inform) {
+  if (!d_b) return solve_common(static_cast<Handle*>(handle), job, nrhs, d_x, ldx, true, inform);
+  return solve_common(static_cast<Handle*>(handle), job, nrhs, d_x, ldx, true, inform, d_b);
 }
 
 int gsls_solve(void* handle, int32_t job, int32_t nrhs, double* x, int32_t ldx, const gsls_options*,

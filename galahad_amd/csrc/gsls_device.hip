@@ -6298,7 +6298,14 @@ static int mr_width(const Symbolic& S, const DeviceFactor& F, int nrhs) {
 }
 
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
-                     int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev) {
+                     int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev, const double* d_b) {
+  // d_b (optional): the right-hand sides live in another device array of the same shape and d_x only receives the
+  // solution.  A whole solve of one column on the wave tier reads them from there directly (its bottom-stage launch
+  // gathers the right-hand side anyway); every other path starts with a device-to-device copy and works in place.
+  const bool b_direct = d_b && d_b != d_x && nrhs == 1 && !posdef && F.wave && S.n > 0 &&
+                        can_fuse_input(F, job, d_scale != nullptr, 1);
+  if (d_b && d_b != d_x && !b_direct && S.n > 0)
+    HIPCHK(hipMemcpyAsync(d_x, d_b, (size_t(ldx) * (nrhs - 1) + S.n) * sizeof(double), hipMemcpyDeviceToDevice, st));
   int r0 = 0;
   if (posdef && nrhs >= 2 && S.n > 0 && !F.sharded && !getenv("GSLS_NO_MULTIRHS")) {
     // blocks of 8 / 4 / 2 columns through the multi-column kernels: one pass over L per block
@@ -6363,7 +6370,7 @@ hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, i
         hipLaunchKernelGGL(k_permute_in, dim3(blocks), dim3(256), 0, st, S.n, F.invp, x,
                            scale_in ? d_scale : nullptr, F.xp);
       e = posdef ? solve_sweeps<true>(S, F, F.plan, job, F.xp, st, evr)
-          : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, fuse_in ? x : nullptr,
+          : wave ? solve_sweeps<false>(S, F, F.planW, job, F.xp, st, evr, -2, true, fuse_in ? (b_direct ? d_b : x) : nullptr,
                                        fuse_out ? x : nullptr, scale_out ? d_scale : nullptr)
                  : solve_sweeps<false>(S, F, F.plan, job, F.xp, st, evr);
       if (e != hipSuccess) return e;

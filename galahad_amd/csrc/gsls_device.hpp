@@ -251,7 +251,7 @@ hipError_t dev_discover(const Symbolic& S, DeviceFactor& F, const double* d_val,
                         std::vector<int32_t>& seq, std::vector<uint8_t>& two, int& status, int& ndelayed);
 hipError_t dev_set_tiny_blacklist(const Symbolic& S, DeviceFactor& F, const std::vector<int>& nodes, hipStream_t st);
 hipError_t dev_solve(const Symbolic& S, DeviceFactor& F, bool posdef, int job, int nrhs, double* d_x,
-                     int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/);
+                     int ldx, const double* d_scale, hipStream_t st, hipEvent_t* ev /*4 or null*/, const double* d_b = nullptr);
 // multi-GPU phases (see gsls_shard_factor / gsls_shard_solve in include/gsls.h)
 hipError_t dev_shard_factor(const Symbolic& S, DeviceFactor& F, int phase, bool posdef, const double* d_val,
                             double* d_xchg, double small, double u, hipStream_t st, bool fast = false);

@@ -216,6 +216,13 @@ int gsls_solve(void* handle, int32_t job, int32_t nrhs, double* x, int32_t ldx,
 int gsls_solve_dev(void* handle, int32_t job, int32_t nrhs, double* d_x, int32_t ldx,
                    const gsls_options* options, gsls_inform* inform);
 
+/* gsls_solve_dev with the right-hand sides in ANOTHER device array of the same shape (d_b, left untouched); d_x only
+ * receives the solution.  A whole solve of one column on the LDL^T wave tier reads d_b directly (no copy); every other
+ * case starts with a device-to-device copy and is gsls_solve_dev on d_x.  An interior-point loop that keeps its
+ * right-hand side for the residual (SLS_solve_ir, SBLS) needs no copy of it. */
+int gsls_solve_dev_rhs(void* handle, int32_t job, int32_t nrhs, const double* d_b, double* d_x, int32_t ldx,
+                       const gsls_options* options, gsls_inform* inform);
+
 /* ---- enquire / alter ----------------------------------------------------------------------------- */
 
 /* replaces ssids_enquire_posdef(akeep, fkeep, options, inform, d)  src/ssids/ssids.f90:1255-1293 */

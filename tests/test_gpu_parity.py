@@ -760,6 +760,59 @@ def test_multi_rhs_columns_in_one_launch_equal_column_by_column(kind, nrhs):
     s.terminate()
 
 
+@pytest.mark.parametrize("kind", ["kkt", "kkt_scaled", "band_spd", "grid_indef"])
+@pytest.mark.parametrize("nrhs", [1, 3])
+def test_solve_with_the_right_hand_side_in_another_device_array(kind, nrhs):
+    """gsls_solve_dev_rhs: b stays where it is (bit for bit), x = the bits of the in-place solve of a copy -- on the wave
+    tier's direct path (one column, whole solve: the bottom-stage launch reads b itself), with a scaling vector, on the
+    Cholesky path and with several columns (those copy first)."""
+    import ctypes as C
+    import torch
+    from galahad_amd import SLS, SMT, Control, InformSLS
+    from galahad_amd._lib import lib, Inform
+    if kind.startswith("kkt"):
+        prob = P.kkt_qpband(5000, 1500, seed=3)
+    elif kind == "band_spd":
+        prob = P.banded_spd(3000, 20)
+    else:
+        prob = P.grid2d(40, 30, shift=1.0)
+    n, row, col, val, rhs, xs = prob
+    s, c, i = SLS(), Control(), InformSLS()
+    s.initialize("gsls", c, i)
+    c.pivot_control, c.node_amalgamation = (2 if kind == "band_spd" else 1), 24
+    if kind == "kkt_scaled":
+        c.scaling = -1
+    m = SMT(n, "COORDINATE", row=row, col=col, val=val)
+    s.analyse(m, c, i)
+    s.factorize(m, c, i)
+    s.factorize(m, c, i)
+    assert i.status == 0
+    rng = np.random.default_rng(5)
+    B = torch.from_numpy(rng.uniform(-1, 1, (nrhs, n))).cuda()           # row k = column k, ldx = n
+    inf = Inform()
+    for job in (0, 1):                                                    # whole solve; forward only (never the direct path)
+        ref = B.clone()
+        assert lib.gsls_solve_dev(s.handle, job, nrhs, C.c_void_p(ref.data_ptr()), n, C.byref(s.opts), C.byref(inf)) >= 0
+        keep = B.clone()
+        X = torch.full_like(B, float("nan"))
+        assert lib.gsls_solve_dev_rhs(s.handle, job, nrhs, C.c_void_p(B.data_ptr()), C.c_void_p(X.data_ptr()), n,
+                                      C.byref(s.opts), C.byref(inf)) >= 0
+        torch.cuda.synchronize()
+        assert torch.equal(B, keep)
+        assert torch.equal(X, ref), (kind, nrhs, job)
+    # d_b = d_x and d_b = NULL are the in-place call
+    Y = B.clone()
+    assert lib.gsls_solve_dev_rhs(s.handle, 0, nrhs, C.c_void_p(Y.data_ptr()), C.c_void_p(Y.data_ptr()), n,
+                                  C.byref(s.opts), C.byref(inf)) >= 0
+    Z = B.clone()
+    assert lib.gsls_solve_dev_rhs(s.handle, 0, nrhs, None, C.c_void_p(Z.data_ptr()), n, C.byref(s.opts), C.byref(inf)) >= 0
+    ref = B.clone()
+    assert lib.gsls_solve_dev(s.handle, 0, nrhs, C.c_void_p(ref.data_ptr()), n, C.byref(s.opts), C.byref(inf)) >= 0
+    torch.cuda.synchronize()
+    assert torch.equal(Y, ref) and torch.equal(Z, ref)
+    s.terminate()
+
+
 @pytest.mark.parametrize("posdef", [False, True])
 def test_multi_rhs_with_padded_leading_dimension(posdef):
     """gsls_solve / gsls_solve_dev take X(ldx, nrhs) with ldx >= n (ssids_solve_mult's ldx, ssids.f90:1139-1160): columns
