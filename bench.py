@@ -317,12 +317,29 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ksolve = []
-    for _ in range(a.steps):
-        step()
+
+    def sweep_seconds():
         kf, kd, kb = C.c_double(), C.c_double(), C.c_double()
         lib.gsls_last_solve_kernel_seconds(s.handle, C.byref(kf), C.byref(kd), C.byref(kb))
-        ksolve.append(kf.value + kd.value + kb.value)
+        return kf.value + kd.value + kb.value
+    # gsls_solve_dev_rhs only enqueues: a step's sweep time (HIP events on the handle's stream) is read one step later,
+    # after that step's factorization has synchronised the stream anyway -- no extra host round trip inside the loop
+    for k in range(a.steps):
+        if tsh is None and k > 0:
+            fs = lib.gsls_factor_dev(s.handle, 1 if posdef else 0, C.c_void_p(d_val.data_ptr()), None, C.byref(s.opts),
+                                     C.byref(ginf))
+            assert fs >= 0, fs
+            ksolve.append(sweep_seconds())
+            fs = lib.gsls_solve_dev_rhs(s.handle, 0, 1, C.c_void_p(d_rhs.data_ptr()), C.c_void_p(d_x.data_ptr()), n,
+                                        C.byref(s.opts), C.byref(ginf))
+            assert fs >= 0, fs
+        else:
+            step()
+            if tsh is not None:
+                ksolve.append(sweep_seconds())
     torch.cuda.synchronize()
+    if tsh is None:
+        ksolve.append(sweep_seconds())
     gdist.barrier(world)
     elapsed = gdist.max_over_ranks(time.perf_counter() - t0, world)
 

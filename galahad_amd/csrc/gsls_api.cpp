@@ -80,6 +80,7 @@ struct Handle {
   int64_t cx_factor_elems = 0, cx_solve_elems = 0, cx_cut_elems = 0;         // the device-side front flags no longer match tppvar / the current tree
   int nemin = 32;
   double kt_fwd = 0, kt_diag = 0, kt_bwd = 0;
+  bool kt_pending = false;        // the last solve was enqueued only: its event times are read on demand
 };
 
 double now() {
@@ -1337,7 +1338,7 @@ int gsls_residual(void* handle, int32_t nrhs, const double* x, int32_t ldx, cons
 }
 
 static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool on_device,
-                        gsls_inform* inform, const double* b_dev = nullptr);
+                        gsls_inform* inform, const double* b_dev = nullptr, bool enqueue_only = false);
 
 // SLS_solve_ir (sls.f90:4770-4949) with every vector resident in HBM: b in, x out, nothing else crosses the bus
 int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double residual_absolute,
@@ -1406,7 +1407,7 @@ int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double resid
 }
 
 static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool on_device,
-                        gsls_inform* inform, const double* b_dev) {
+                        gsls_inform* inform, const double* b_dev, bool enqueue_only) {
   gsls_inform local;
   if (!inform) inform = &local;
   if (!h || !h->analysed || !h->factored) {
@@ -1463,8 +1464,17 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
     e = hipMemcpyAsync(x, F.xhost, xelems * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e != hipSuccess) return fail_hip(h, inform, e);
   }
+  if (enqueue_only && on_device) {
+    // device operands: the solve is stream-ordered work on the handle's stream -- whatever the caller enqueues next on this
+    // handle (the next factorization of an interior-point loop) follows it without the GPU waiting for the host in between
+    h->kt_pending = true;
+    inform->time_solve = now() - t0;
+    inform->solve_bytes = 2 * 8 * S.num_factor + (h->posdef ? 0 : 16 * int64_t(S.n)) + 32 * int64_t(S.n);
+    return inform->flag;
+  }
   e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return fail_hip(h, inform, e);
+  h->kt_pending = false;
   float ms = 0;
   static const bool phase_events = getenv("GSLS_SOLVE_PHASES") != nullptr;
   if (phase_events) {
@@ -1484,8 +1494,7 @@ static int solve_common(Handle* h, int job, int nrhs, double* x, int ldx, bool o
 
 int gsls_solve_dev_rhs(void* handle, int32_t job, int32_t nrhs, const double* d_b, double* d_x, int32_t ldx,
                        const gsls_options*, gsls_inform* inform) {
-  if (!d_b) return solve_common(static_cast<Handle*>(handle), job, nrhs, d_x, ldx, true, inform);
-  return solve_common(static_cast<Handle*>(handle), job, nrhs, d_x, ldx, true, inform, d_b);
+  return solve_common(static_cast<Handle*>(handle), job, nrhs, d_x, ldx, true, inform, d_b, true);
 }
 
 int gsls_solve(void* handle, int32_t job, int32_t nrhs, double* x, int32_t ldx, const gsls_options*,
@@ -2260,6 +2269,23 @@ void* gsls_get_stream(void* handle) {
 int gsls_last_solve_kernel_seconds(void* handle, double* fwd, double* diag, double* bwd) {
   Handle* h = static_cast<Handle*>(handle);
   if (!h) return GSLS_ERROR_CALL_SEQUENCE;
+  if (h->kt_pending) {            // (an enqueue-only solve: wait for its last event now)
+    DeviceGuard g(h->device);
+    float ms = 0;
+    if (h->ev[3] && hipEventSynchronize(h->ev[3]) == hipSuccess) {
+      static const bool phase_events = getenv("GSLS_SOLVE_PHASES") != nullptr;
+      if (phase_events) {
+        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->kt_fwd = ms * 1e-3;
+        if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->kt_diag = ms * 1e-3;
+        if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->kt_bwd = ms * 1e-3;
+      } else {
+        h->kt_diag = h->kt_bwd = 0.0;
+        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[3]) == hipSuccess) h->kt_fwd = ms * 1e-3;
+      }
+    }
+    (void)hipGetLastError();
+    h->kt_pending = false;
+  }
   if (fwd) *fwd = h->kt_fwd;
   if (diag) *diag = h->kt_diag;
   if (bwd) *bwd = h->kt_bwd;

@@ -219,7 +219,11 @@ int gsls_solve_dev(void* handle, int32_t job, int32_t nrhs, double* d_x, int32_t
 /* gsls_solve_dev with the right-hand sides in ANOTHER device array of the same shape (d_b, left untouched); d_x only
  * receives the solution.  A whole solve of one column on the LDL^T wave tier reads d_b directly (no copy); every other
  * case starts with a device-to-device copy and is gsls_solve_dev on d_x.  An interior-point loop that keeps its
- * right-hand side for the residual (SLS_solve_ir, SBLS) needs no copy of it. */
+ * right-hand side for the residual (SLS_solve_ir, SBLS) needs no copy of it.
+ * ENQUEUE ONLY: the call returns when the work is on the handle's stream (gsls_get_stream), not when it has run --
+ * the next call on this handle is ordered behind it (so a factorization can be enqueued while the solve runs, no host
+ * round trip in between); to read d_x from another stream or from the host, synchronise with the handle's stream
+ * first.  Errors of the enqueued kernels surface in the next call that synchronises. */
 int gsls_solve_dev_rhs(void* handle, int32_t job, int32_t nrhs, const double* d_b, double* d_x, int32_t ldx,
                        const gsls_options* options, gsls_inform* inform);
 
