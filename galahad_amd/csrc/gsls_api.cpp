@@ -1381,21 +1381,25 @@ int gsls_solve_ir(void* handle, double* x, int32_t max_refinements, double resid
     return e2;
   };
   e = hipMemcpyAsync(dB, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(dR, dB, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(dX, 0, n * sizeof(double), h->stream);
   double residual_zero = 0.0, residual = 0.0;
-  if (e == hipSuccess) e = max_abs(dB, residual_zero);
+  // (every max_abs is a host round trip: the norm of b only where a relative tolerance needs it)
+  if (e == hipSuccess && residual_relative > 0.0 && max_refinements > 0) e = max_abs(dB, residual_zero);
   if (e != hipSuccess) return fail_hip(h, inform, e);
   for (int iter = 0; iter <= std::max(max_refinements, 0); ++iter) {
     if (iterations) *iterations = iter;
     gsls_inform si;
-    const int f = solve_common(h, GSLS_SOLVE_JOB_ALL, 1, dR, n, true, &si);
+    // stream-ordered, no host synchronisation: the solves, the update and the residual follow each other on the handle's
+    // stream; the first solve reads b where it lies (solve_common: b_dev) and writes into dR, the later ones refine dR
+    const int f = solve_common(h, GSLS_SOLVE_JOB_ALL, 1, dR, n, true, &si, iter == 0 ? dB : nullptr, true);
     if (f < 0) {
       *inform = si;
       return f;
     }
     e = dev_vec_add(n, dX, dR, h->stream);
-    if (e == hipSuccess && iter < max_refinements) e = dev_residual(F, n, 1, dX, n, dB, n, dR, n, h->stream);
+    if (e != hipSuccess) return fail_hip(h, inform, e);
+    if (iter >= max_refinements) break;          // (no step may follow: its residual would serve nothing)
+    e = dev_residual(F, n, 1, dX, n, dB, n, dR, n, h->stream);
     if (e == hipSuccess) e = max_abs(dR, residual);
     if (e != hipSuccess) return fail_hip(h, inform, e);
     if (residual < std::max(residual_absolute, residual_relative * residual_zero)) break;
