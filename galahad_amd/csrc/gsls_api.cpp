@@ -888,7 +888,11 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
       if (st[4] > 0) ++learn_fail;
       just_learned = false;
     }
-    if (!posdef && st[4] == 0 && h->learned < 3 && h->learn_strikes < 2 && learn_fail == 0 && (st[7] > 0 || st[14] > 0)) {
+    // (not after a discovery in this call: its sequence is a learned one already, and folding the few blocks that still
+    // pivot into it has been seen to undo it -- thousands of fronts back on the blacklist, four or five more passes)
+    static const bool learn_after_disc = getenv("GSLS_LEARN_AFTER_DISCOVERY") != nullptr;
+    if (!posdef && st[4] == 0 && h->learned < 3 && h->learn_strikes < 2 && learn_fail == 0 && (st[7] > 0 || st[14] > 0) &&
+        (!disc_ok || learn_after_disc)) {
       just_learned = true;
       // ---- learn: fold the pivot sequence the pivoting kernels chose inside their blocks / fronts into the
       // elimination order, and remember where they took 2x2 pivots, so that later factorizations of
