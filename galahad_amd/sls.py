@@ -437,7 +437,9 @@ class SLS:
         inform.status = _status_from_flag(flag)
         if want_perm or want_pivots:
             out["PIVOTS"] = piv
-            out["PERM"] = np.abs(piv)
+            # PERM = the order the factors are in (data%ORDER, refreshed from the backend after every factorization: the
+            # facade arm of integration/patch_sls.py does the same); PIVOTS adds the pivoting inside the fronts
+            out["PERM"] = self.ORDER.copy()
         if want_d:
             out["D"] = d
         return out
