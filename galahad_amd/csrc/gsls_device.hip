@@ -5453,7 +5453,9 @@ static hipError_t factor_levels(const Symbolic& S, DeviceFactor& F, const std::v
   if (zbase > 0) zero_c = true;
   for (int l = 0; l < S.nlevels; ++l) {
     const LevelPlan& lp = plan[l];
-    if (zero_c && F.cz_cnt[zbase + l] > 0)     // the contribution blocks this level's fronts own (arena space is reused)
+    // (a pass on the wave-per-front kernels only writes every contribution block whole, once: nothing to clear)
+    const bool all_wave = !POSDEF && &plan == &F.planT && F.nscatter_wg == 0 && F.bl_count == 0 && zbase == 0;
+    if (zero_c && !all_wave && F.cz_cnt[zbase + l] > 0)     // the contribution blocks this level's fronts own (arena space is reused)
       hipLaunchKernelGGL(k_zero_tasks, dim3(F.cz_cnt[zbase + l]), dim3(256), 0, st,
                          static_cast<const ZeroTask*>(F.cztasks) + F.cz_begin[zbase + l], F.C);
     if (lp.pull_cnt > 0)
