@@ -783,7 +783,12 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
   int tiny_repeats = 0;
   const int max_pass = 60;    // a variable fails at most three times (plan_repair); cascades end long before this
   int pending_flags = 0;      // columns the last repair flagged for whole-front pivoting (without moving them)
-  bool discovered = false;    // the pivot-order discovery sweep has run in this call (dev_discover)
+  // pivot-order discovery sweeps of this call (dev_discover).  Two by default: what the static kernels still fail after the
+  // first (a few dozen columns on CQP's systems) is found in one more sweep where the repair loop needs three re-analyses
+  // (41 -> 4 -> 1 -> 0 failing columns); a third sweep costs more than it saves (CQP N = 1e5, SLS_factorize over ten
+  // iterations, four runs each: one sweep 0.80 s, two 0.70 s, three 0.95 s)
+  int discovered = 0;
+  static const int max_discover = getenv("GSLS_MAX_DISCOVER") ? atoi(getenv("GSLS_MAX_DISCOVER")) : 2;
   bool disc_ok = false;       // ... and its sequence was adopted
   bool just_learned = false;  // the previous pass ended in a learning round
   int learn_fail = 0;         // learning rounds of this call after which pivots failed
@@ -964,8 +969,8 @@ static int factor_common(Handle* h, int posdef, const double* val, const double*
     // find the elimination sequence threshold partial pivoting WITH run-time delays gives for these values
     // (k_front_discover: one bottom-up sweep, failed columns travel to the parent inside it, as in the reference),
     // adopt it as the order + 2x2 hints, re-analyse once and factorize again on the static kernels ---------------------
-    if (!discovered && !scale && !getenv("GSLS_NO_DISCOVER")) {
-      discovered = true;
+    if (discovered < max_discover && !scale && !getenv("GSLS_NO_DISCOVER")) {
+      ++discovered;
       std::vector<int32_t> seq;
       std::vector<uint8_t> two;
       int dstat = 1, ndel = 0;
